@@ -1,0 +1,196 @@
+/*
+ * vrm.h -- C ABI of the MI355X ray-marching path ("vrm" = volume ray marcher).
+ *
+ * This is the drop-in boundary for the one hot path of bennetde/volume-renderer: everything the
+ * Rust host (`State`, src/state.rs) asks of `RayMarcher`, `VoxelGrid`, `Texture3D` and
+ * `Screenshotter` is one call here.  The reference has no FFI of its own; each entry point cites
+ * the Rust interface it replaces (paths relative to the reference's src/).  INTEGRATION.md shows the
+ * `extern "C"` block a `vrm-sys` crate would declare.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; opaque handles; no C++/torch types.
+ *   - every function returns 0 on success or a negative vrm_status; vrm_last_error() returns a
+ *     thread-local message for the last failure.  Nothing aborts across the boundary (the reference
+ *     panics / unwrap()s: grid.rs:209, screenshot.rs:81, state.rs:273).
+ *   - a vrm_ctx is bound to one GPU and is not thread-safe (the reference is single-threaded:
+ *     Rc<BindGroup>, ray_marcher/mod.rs:21).  Different contexts may be used from different threads.
+ *   - host pointers passed in are copied before the call returns unless stated otherwise.
+ *   - the library fails loudly (VRM_ERR_NO_DEVICE) when no HIP device is present; there is no CPU
+ *     fallback of any kind.
+ */
+#ifndef VRM_H
+#define VRM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRM_API __attribute__((visibility("default")))
+
+typedef enum vrm_status {
+    VRM_OK = 0,
+    VRM_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, size mismatch) */
+    VRM_ERR_NO_DEVICE = -2, /* no usable HIP device */
+    VRM_ERR_HIP = -3,       /* a HIP runtime call failed; see vrm_last_error() */
+    VRM_ERR_IO = -4,        /* file could not be read / written / parsed */
+    VRM_ERR_STATE = -5      /* call made in the wrong state (e.g. map before readback) */
+} vrm_status;
+
+/* ---- byte-exact uniform structs ---------------------------------------------------------- */
+
+/* CameraUniform, camera.rs:42-50 / raymarcher.wgsl:2-6.  144 bytes, matrices column-major. */
+typedef struct vrm_camera_uniform {
+    float position[4];          /* xyz, w = 0 */
+    float view_proj[16];        /* unused by the march, carried for layout parity */
+    float inverse_view_proj[16];
+} vrm_camera_uniform;
+
+/* RaymarchTransferFunctionColors, voxel/grid.rs:34-41 / raymarcher.wgsl:22-27.  64 bytes. */
+typedef struct vrm_transfer_function {
+    float color_a[4];
+    float color_b[4];
+    float color_c[4];
+    uint32_t use_transfer_function[4]; /* [0] != 0 => on */
+} vrm_transfer_function;
+
+/* VoxelGridUniform, voxel/grid.rs:24-32 / raymarcher.wgsl:14-20.  64 bytes. */
+typedef struct vrm_grid_uniform {
+    uint32_t dimensions[4]; /* X, Y, Z, X */
+    float box_min[4];
+    float box_size[4];
+    float buffer[4];        /* attenuation x4 */
+} vrm_grid_uniform;
+
+/* SurfaceConfiguration fields RayMarcher::new / Screenshotter::new read (state.rs:72-84). */
+typedef struct vrm_config {
+    int32_t device_id; /* HIP device ordinal */
+    uint32_t width;    /* default target size, used by vrm_export_sphere */
+    uint32_t height;
+} vrm_config;
+
+typedef struct vrm_ctx vrm_ctx;     /* RayMarcher + its VoxelGrid (ray_marcher/mod.rs:18-23) */
+typedef struct vrm_image vrm_image; /* render target + Screenshotter buffer (screenshot.rs:6-8) */
+
+/* ---- RayMarcher --------------------------------------------------------------------------- */
+
+/* RayMarcher::new (ray_marcher/mod.rs:26-111).  Creates the context with the reference's start-up
+ * grid: 3x3x3, every voxel [0,0,0,255], attenuation 1.0, transfer function off (mod.rs:29,
+ * voxel.rs:13-16, grid.rs:197-198). */
+VRM_API int vrm_create(const vrm_config *config, vrm_ctx **out_ctx);
+VRM_API void vrm_destroy(vrm_ctx *ctx);
+
+/* RayMarcher::draw (ray_marcher/mod.rs:113-141).  Enqueues one view into `target` (cleared to
+ * transparent, REPLACE blend => every pixel is overwritten) and returns without waiting, like the
+ * unsubmitted CommandBuffer the reference returns; completion is observed by vrm_image_map or
+ * vrm_synchronize. */
+VRM_API int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *target);
+
+/* n independent draws in one launch (the export loop state.rs:227-239 + 382-397 issues them one
+ * frame at a time).  cameras[i] renders into targets[i]; all targets must have the same size. */
+VRM_API int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets);
+
+/* device.poll(Maintain::wait()) (screenshot.rs:62): block until everything enqueued on ctx is done. */
+VRM_API int vrm_synchronize(vrm_ctx *ctx);
+
+/* ---- VoxelGrid / Texture3D ---------------------------------------------------------------- */
+
+/* VoxelGrid::new (voxel/grid.rs:44-200) as the loaders call it (dat.rs:57, netcdf.rs:47): new
+ * X*Y*Z grid of default voxels; attenuation resets to 1.0 (grid.rs:100,197); the transfer-function
+ * struct resets to its defaults (grid.rs:198). */
+VRM_API int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z);
+
+/* set_color over the whole grid + update_buffer (grid.rs:202-238, Texture3D::from_image
+ * texture_3d.rs:22-80): RGBA8 voxels, x fastest (idx = x + X*(y + Y*z)), nbytes must be 4*X*Y*Z. */
+VRM_API int vrm_grid_upload_rgba8(vrm_ctx *ctx, const uint8_t *host_voxels, size_t nbytes);
+/* same, source already in this GPU's memory (e.g. after an RCCL broadcast); enqueued on ctx's stream. */
+VRM_API int vrm_grid_upload_rgba8_device(vrm_ctx *ctx, const void *device_voxels, size_t nbytes);
+
+/* loaders/netcdf.rs:45-61: f32 `color(c, z, y, x)`; each value becomes `(v*255.0) as u8`
+ * (truncate, saturate, NaN -> 0).  channels = 4, or 1 for a scalar field replicated to r=g=b=a. */
+VRM_API int vrm_grid_upload_f32(vrm_ctx *ctx, const float *host_czyx, uint32_t channels);
+VRM_API int vrm_grid_upload_f32_device(vrm_ctx *ctx, const void *device_czyx, uint32_t channels);
+
+/* loaders/dat.rs:58-76 quantisation: raw UCHAR (bytes_per_sample 1) or USHORT combined big-endian
+ * (bytes_per_sample 2); voxel = [b,b,b,b]. */
+VRM_API int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, size_t nbytes, uint32_t bytes_per_sample);
+
+/* Index<UVec3> over the whole grid (grid.rs:249-263): copies the RGBA8 voxels back, x fastest. */
+VRM_API int vrm_grid_download_rgba8(vrm_ctx *ctx, uint8_t *host_voxels, size_t nbytes);
+
+/* voxel_grid.attenuation + update_voxel_grid_buffer (grid.rs:20,240-242; state.rs:365-368) */
+VRM_API int vrm_set_attenuation(vrm_ctx *ctx, float attenuation);
+/* transfer_function_colors + update_transfer_function_buffer (grid.rs:21,244-246; state.rs:370-374) */
+VRM_API int vrm_set_transfer_function(vrm_ctx *ctx, const vrm_transfer_function *tf);
+/* the VoxelGridUniform the shader would see (grid.rs:265-280) */
+VRM_API int vrm_get_grid_uniform(vrm_ctx *ctx, vrm_grid_uniform *out);
+
+/* ---- Screenshotter ------------------------------------------------------------------------ */
+
+/* Screenshotter::new (screenshot.rs:12-27) plus the surface texture it copies from: an RGBA8
+ * (non-sRGB, state.rs:78) target of w*h pixels, device + pinned host copy, row pitch
+ * ceil(4w/256)*256 bytes (screenshot.rs:94-96). */
+VRM_API int vrm_image_create(vrm_ctx *ctx, uint32_t width, uint32_t height, vrm_image **out_image);
+VRM_API void vrm_image_destroy(vrm_image *image);
+/* Screenshotter::screenshot (screenshot.rs:30-54): enqueue the device->host copy behind the draws. */
+VRM_API int vrm_image_readback_async(vrm_image *image);
+/* map_async + poll(wait) + get_mapped_range (screenshot.rs:58-65): blocks until the copy landed.
+ * *rgba8 stays valid until vrm_image_unmap; rows are *pitch bytes apart. */
+VRM_API int vrm_image_map(vrm_image *image, const uint8_t **rgba8, size_t *pitch);
+VRM_API int vrm_image_unmap(vrm_image *image); /* screenshot.rs:91 */
+/* save_screenshot_to_disk (screenshot.rs:57-92): readback if needed, strip row padding, write an
+ * RGBA8 PNG (premultiplied colour + alpha, as rendered). */
+VRM_API int vrm_image_save_png(vrm_image *image, const char *path);
+
+/* ---- camera + export loop (host side of the path) ------------------------------------------ */
+
+/* CameraUniform::update_view_proj (camera.rs:61-67) for a camera at `position` aimed by
+ * Transform::look_to(target, +Y) (transform.rs:59-63), fovy 45 deg, near 0.1, far 1000 (camera.rs:19-21).
+ * basis9 (may be NULL) receives right, up, front as written to cameras.json. */
+VRM_API int vrm_camera_look_at(const float position[3], const float target[3], float aspect, vrm_camera_uniform *out,
+                               float basis9[9]);
+/* CameraSphereController::get_position_on_sphere (camera_sphere_controller.rs:79-89) */
+VRM_API int vrm_sphere_position(uint32_t ix, uint32_t iy, uint32_t x_div, uint32_t y_div, float radius,
+                                const float origin[3], float out_position[3]);
+
+/* "Screenshot All" (sphere_screenshot_manager.rs:23-73, state.rs:318-322,391-397): renders the
+ * x_div*(y_div-1) views (y outer from 1, x inner), writes `<out_dir>/<ix>-<iy>.png` and
+ * `<out_dir>/cameras.json`.  Of that list this context renders views i with i % n_parts == part
+ * (view partitioning over GPUs/ranks); only part 0 writes cameras.json.  Uses ctx's default size. */
+VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, float radius, const float origin[3],
+                              const char *out_dir, uint32_t part, uint32_t n_parts);
+
+/* loaders/dat.rs:10-82: parse `ObjectFileName/Resolution/Format`, read the RAW next to it, upload. */
+VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
+
+/* ---- build extensions (no reference counterpart; off unless asked for) ---------------------- */
+
+typedef enum vrm_option {
+    VRM_OPT_KERNEL = 0,       /* kernel variant; 0 = default */
+    VRM_OPT_SKIP_EMPTY = 1,   /* exact empty-space skipping (skipped samples contribute exactly 0) */
+    VRM_OPT_PROFILE = 2,      /* record hipEvents around every march launch */
+    VRM_OPT_DIAGNOSTICS = 3   /* also write per-pixel f32 colour and iteration counts */
+} vrm_option;
+VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
+VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);
+
+/* With VRM_OPT_PROFILE on: total device time (hipEvent, on the stream the kernels were launched
+ * on) and number of march launches since the last reset. */
+VRM_API int vrm_profile_read(vrm_ctx *ctx, double *kernel_ms, uint64_t *launches, int reset);
+
+/* With VRM_OPT_DIAGNOSTICS on at draw time: premultiplied f32 RGBA (w*h*4 floats) and per-ray loop
+ * iteration counts (w*h u32) of the last draw into `image`; either pointer may be NULL. */
+VRM_API int vrm_image_read_diagnostics(vrm_image *image, float *rgba_f32, uint32_t *iterations);
+/* Same switch: 8 floats per pixel -- ray direction xyz, t_min, t_max, number of samples that passed the
+ * in-box test (wgsl:218-223), hit flag (wgsl:131), 0 -- so tests can check the geometry bit for bit. */
+VRM_API int vrm_image_read_ray_diagnostics(vrm_image *image, float *geom8);
+
+VRM_API const char *vrm_last_error(void);
+VRM_API const char *vrm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRM_H */

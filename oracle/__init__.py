@@ -1,0 +1,177 @@
+"""ctypes loader for the CPU oracle (oracle/vr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (volume_renderer_amd).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
+_lib = None
+
+# RaymarchTransferFunctionColors::new (reference src/voxel/grid.rs:282-290)
+DEFAULT_TF_COLORS = (
+    (0.117, 0.188, 0.62, 1.0),
+    (0.7294, 0.7294, 0.7294, 1.0),
+    (0.5725, 0.0, 0.039, 1.0),
+)
+
+
+def build(force=False):
+    """Compile libvr_oracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "vr_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libvr_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        L.orc_camera_uniform.argtypes = [f32p, f32p, ctypes.c_float, f32p, f32p]
+        L.orc_camera_uniform.restype = None
+        L.orc_sphere_position.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_float, f32p, f32p]
+        L.orc_sphere_position.restype = None
+        L.orc_grid_uniform.argtypes = [u32p, ctypes.c_float, u32p, f32p, f32p, f32p]
+        L.orc_grid_uniform.restype = None
+        L.orc_quantize_dat.argtypes = [u8p, ctypes.c_size_t, ctypes.c_int, u8p]
+        L.orc_quantize_dat.restype = None
+        L.orc_quantize_netcdf.argtypes = [f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u8p]
+        L.orc_quantize_netcdf.restype = None
+        L.orc_render.argtypes = [u8p, u32p, f32p, u32p, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32,
+                                 f32p, u8p, u32p, ctypes.c_int]
+        L.orc_render.restype = ctypes.c_uint64
+        L.orc_scene.argtypes = [u8p, u32p, f32p, f32p]
+        L.orc_scene.restype = None
+        L.orc_ray.argtypes = [f32p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                              f32p, f32p, f32p]
+        L.orc_ray.restype = ctypes.c_int
+        L.orc_max_threads.restype = ctypes.c_int
+        L.orc_geometry.argtypes = [f32p, u32p, ctypes.c_uint32, ctypes.c_uint32, f32p]
+        L.orc_geometry.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ctypes.POINTER(ty))
+
+
+def camera_uniform(position, target=(0.0, 0.0, 0.0), aspect=1.0, with_basis=False):
+    """CameraUniform (36 f32: position[4], view_proj[16], inverse_view_proj[16]) for a camera at
+    `position` aimed at `target` with up=+Y (reference camera.rs:61-67, transform.rs:59-63)."""
+    pos = np.asarray(position, dtype=np.float32)
+    tgt = np.asarray(target, dtype=np.float32)
+    out = np.zeros(36, dtype=np.float32)
+    basis = np.zeros(9, dtype=np.float32)
+    lib().orc_camera_uniform(_p(pos, ctypes.c_float), _p(tgt, ctypes.c_float), ctypes.c_float(aspect),
+                             _p(out, ctypes.c_float), _p(basis, ctypes.c_float))
+    return (out, basis.reshape(3, 3)) if with_basis else out
+
+
+def sphere_position(ix, iy, xdiv, ydiv, radius, origin=(0.0, 0.0, 0.0)):
+    org = np.asarray(origin, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_sphere_position(ix, iy, xdiv, ydiv, ctypes.c_float(radius), _p(org, ctypes.c_float), _p(out, ctypes.c_float))
+    return out
+
+
+def sphere_views(xdiv, ydiv):
+    """View order of the export loop (sphere_screenshot_manager.rs:23-54): y outer 1..ydiv-1, x inner."""
+    return [(ix, iy) for iy in range(1, ydiv) for ix in range(xdiv)]
+
+
+def grid_uniform(dims, attenuation=1.0):
+    d = np.asarray(dims, dtype=np.uint32)
+    od = np.zeros(4, dtype=np.uint32)
+    bmin = np.zeros(4, dtype=np.float32)
+    bsz = np.zeros(4, dtype=np.float32)
+    buf = np.zeros(4, dtype=np.float32)
+    lib().orc_grid_uniform(_p(d, ctypes.c_uint32), ctypes.c_float(attenuation), _p(od, ctypes.c_uint32),
+                           _p(bmin, ctypes.c_float), _p(bsz, ctypes.c_float), _p(buf, ctypes.c_float))
+    return od, bmin, bsz, buf
+
+
+def tf_words(use_tf=False, colors=DEFAULT_TF_COLORS):
+    """RaymarchTransferFunctionColors as 16 32-bit words (grid.rs:34-41)."""
+    w = np.zeros(16, dtype=np.uint32)
+    w[:12] = np.asarray(colors, dtype=np.float32).reshape(12).view(np.uint32)
+    w[12] = 1 if use_tf else 0
+    return w
+
+
+def quantize_dat(raw, bytes_per_sample=1):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1)
+    n = raw.size // bytes_per_sample
+    out = np.zeros(n * 4, dtype=np.uint8)
+    lib().orc_quantize_dat(_p(raw, ctypes.c_uint8), n, bytes_per_sample, _p(out, ctypes.c_uint8))
+    return out.reshape(n, 4)
+
+
+def quantize_netcdf(data_czyx):
+    """f32 color(c=4,z,y,x) -> RGBA8 voxels shaped (Z,Y,X,4) (x fastest)."""
+    d = np.ascontiguousarray(data_czyx, dtype=np.float32)
+    _, Z, Y, X = d.shape
+    out = np.zeros((Z, Y, X, 4), dtype=np.uint8)
+    lib().orc_quantize_netcdf(_p(d, ctypes.c_float), X, Y, Z, _p(out, ctypes.c_uint8))
+    return out
+
+
+def render(voxels_zyxc, cam36, width, height, attenuation=1.0, tf=None, want_f32=True, want_steps=False, threads=None):
+    """Render one view. voxels_zyxc: uint8 array shaped (Z,Y,X,4). Returns dict(rgba8, f32, steps, samples)."""
+    v = np.ascontiguousarray(voxels_zyxc, dtype=np.uint8)
+    Z, Y, X, C = v.shape
+    assert C == 4
+    dims = np.array([X, Y, Z], dtype=np.uint32)
+    cam = np.ascontiguousarray(cam36, dtype=np.float32)
+    tfw = tf_words() if tf is None else np.ascontiguousarray(tf, dtype=np.uint32)
+    rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
+    f32 = np.zeros((height, width, 4), dtype=np.float32) if want_f32 else None
+    steps = np.zeros((height, width), dtype=np.uint32) if want_steps else None
+    if threads is None:
+        threads = min(lib().orc_max_threads(), os.cpu_count() or 1)
+    total = lib().orc_render(_p(v, ctypes.c_uint8), _p(dims, ctypes.c_uint32), _p(cam, ctypes.c_float),
+                             _p(tfw, ctypes.c_uint32), ctypes.c_float(attenuation), width, height,
+                             _p(f32, ctypes.c_float) if want_f32 else None, _p(rgba8, ctypes.c_uint8),
+                             _p(steps, ctypes.c_uint32) if want_steps else None, int(threads))
+    return {"rgba8": rgba8, "f32": f32, "steps": steps, "samples": int(total)}
+
+
+def scene(voxels_zyxc, p):
+    v = np.ascontiguousarray(voxels_zyxc, dtype=np.uint8)
+    Z, Y, X, _ = v.shape
+    dims = np.array([X, Y, Z], dtype=np.uint32)
+    pp = np.asarray(p, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    lib().orc_scene(_p(v, ctypes.c_uint8), _p(dims, ctypes.c_uint32), _p(pp, ctypes.c_float), _p(out, ctypes.c_float))
+    return out
+
+
+def ray(cam36, dims_xyz, px, py, width, height):
+    cam = np.ascontiguousarray(cam36, dtype=np.float32)
+    dims = np.asarray(dims_xyz, dtype=np.uint32)
+    rd = np.zeros(3, dtype=np.float32)
+    tmin = ctypes.c_float()
+    tmax = ctypes.c_float()
+    hit = lib().orc_ray(_p(cam, ctypes.c_float), _p(dims, ctypes.c_uint32), px, py, width, height, _p(rd, ctypes.c_float),
+                        ctypes.byref(tmin), ctypes.byref(tmax))
+    return bool(hit), rd, tmin.value, tmax.value
+
+
+def geometry(cam36, dims_xyz, width, height):
+    """(H, W, 8) f32 per ray: rd.xyz, t_min, t_max, n_inside (no early termination), hit, iterations."""
+    cam = np.ascontiguousarray(cam36, dtype=np.float32)
+    dims = np.asarray(dims_xyz, dtype=np.uint32)
+    out = np.zeros((height, width, 8), dtype=np.float32)
+    lib().orc_geometry(_p(cam, ctypes.c_float), _p(dims, ctypes.c_uint32), width, height, _p(out, ctypes.c_float))
+    return out

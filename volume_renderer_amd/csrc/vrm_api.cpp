@@ -1,0 +1,587 @@
+// vrm_api.cpp -- the C ABI of include/vrm.h: context, voxel grid, render targets, draw.
+// Compiled with hipcc; uses the HIP runtime API only (no torch, no CPU fallback).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "vrm_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void vrm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int vrm_check_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return VRM_OK;
+    vrm_set_error("%s: %s", what, hipGetErrorString(e));
+    return VRM_ERR_HIP;
+}
+
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        int rc_ = vrm_check_hip((call), #call);           \
+        if (rc_ != VRM_OK) return rc_;                    \
+    } while (0)
+
+#define REQUIRE(cond, ...)                                \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            vrm_set_error(__VA_ARGS__);                   \
+            return VRM_ERR_INVALID;                       \
+        }                                                 \
+    } while (0)
+
+static const uint32_t kViewRing = 4096; // descriptor ring slots
+
+extern "C" const char *vrm_last_error(void) { return g_err; }
+extern "C" const char *vrm_version(void) { return "vrm 0.1 (gfx950)"; }
+
+// RaymarchTransferFunctionColors::new (grid.rs:282-290)
+static void tf_defaults(vrm_transfer_function *tf)
+{
+    const float a[4] = {0.117f, 0.188f, 0.62f, 1.0f}, b[4] = {0.7294f, 0.7294f, 0.7294f, 1.0f}, c[4] = {0.5725f, 0.0f, 0.039f, 1.0f};
+    memcpy(tf->color_a, a, 16);
+    memcpy(tf->color_b, b, 16);
+    memcpy(tf->color_c, c, 16);
+    memset(tf->use_transfer_function, 0, 16);
+}
+
+static int bind(vrm_ctx *ctx)
+{
+    REQUIRE(ctx != nullptr, "null context");
+    return vrm_check_hip(hipSetDevice(ctx->device), "hipSetDevice");
+}
+
+static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
+{
+    REQUIRE(x > 0 && y > 0 && z > 0, "grid dimensions must be non-zero (got %u x %u x %u)", x, y, z);
+    const size_t words = (size_t)x * y * z;
+    REQUIRE(words < ((size_t)1 << 40), "grid too large");
+    // draws in flight still read the old volume: they are on ctx->stream, so order the free behind them
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->vox) HIP_TRY(hipFree(ctx->vox));
+    ctx->vox = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
+    ctx->vox_words = words;
+    ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
+    return VRM_OK;
+}
+
+extern "C" int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    rc = grid_alloc(ctx, x, y, z);
+    if (rc) return rc;
+    // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
+    HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
+    ctx->scalar = false;
+    ctx->attenuation = 1.0f;   // grid.rs:100,197
+    tf_defaults(&ctx->tf);     // grid.rs:198
+    return VRM_OK;
+}
+
+extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
+{
+    REQUIRE(config != nullptr && out_ctx != nullptr, "vrm_create: null argument");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        vrm_set_error("no HIP device available (%s); this library has no CPU fallback",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return VRM_ERR_NO_DEVICE;
+    }
+    REQUIRE(config->device_id >= 0 && config->device_id < n, "device_id %d out of range (have %d)", config->device_id, n);
+    vrm_ctx *ctx = new (std::nothrow) vrm_ctx();
+    REQUIRE(ctx != nullptr, "out of host memory");
+    ctx->device = config->device_id;
+    ctx->def_width = config->width ? config->width : 1024;   // lib.rs:34 default window
+    ctx->def_height = config->height ? config->height : 1024;
+    tf_defaults(&ctx->tf);
+    int rc = VRM_OK;
+    do {
+        if ((rc = vrm_check_hip(hipSetDevice(ctx->device), "hipSetDevice"))) break;
+        if ((rc = vrm_check_hip(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
+        if ((rc = vrm_check_hip(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
+        if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
+        if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
+        if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
+                                "hipHostMalloc")))
+            break;
+        ctx->views_cap = 0; // ring write position
+        if ((rc = vrm_grid_resize(ctx, 3, 3, 3))) break; // ray_marcher/mod.rs:29
+    } while (0);
+    if (rc) {
+        vrm_destroy(ctx);
+        return rc;
+    }
+    *out_ctx = ctx;
+    return VRM_OK;
+}
+
+extern "C" void vrm_destroy(vrm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (auto &p : ctx->prof_events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (ctx->vox) (void)hipFree(ctx->vox);
+    if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->views_dev) (void)hipFree(ctx->views_dev);
+    if (ctx->views_host) (void)hipHostFree(ctx->views_host);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+}
+
+// after new voxel data: is the volume scalar (r == g == b == a)?  (selects the 1-channel filter)
+static int grid_finish_upload(vrm_ctx *ctx)
+{
+    HIP_TRY(hipMemsetAsync(ctx->flag_dev, 0, 4, ctx->stream));
+    HIP_TRY(vrm_launch_detect_nonscalar(ctx->vox, ctx->vox_words, ctx->flag_dev, ctx->stream));
+    uint32_t flag = 1;
+    HIP_TRY(hipMemcpyAsync(&flag, ctx->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->scalar = (flag == 0);
+    return VRM_OK;
+}
+
+extern "C" int vrm_grid_upload_rgba8(vrm_ctx *ctx, const uint8_t *host_voxels, size_t nbytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(host_voxels != nullptr, "null voxel pointer");
+    REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    HIP_TRY(hipMemcpyAsync(ctx->vox, host_voxels, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return grid_finish_upload(ctx);
+}
+
+extern "C" int vrm_grid_upload_rgba8_device(vrm_ctx *ctx, const void *device_voxels, size_t nbytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(device_voxels != nullptr, "null voxel pointer");
+    REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    HIP_TRY(hipMemcpyAsync(ctx->vox, device_voxels, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return grid_finish_upload(ctx);
+}
+
+static int upload_f32_common(vrm_ctx *ctx, const float *dev_src, uint32_t channels)
+{
+    HIP_TRY(vrm_launch_quantize_f32(dev_src, channels, ctx->vox_words, ctx->vox, ctx->stream));
+    return grid_finish_upload(ctx);
+}
+
+extern "C" int vrm_grid_upload_f32(vrm_ctx *ctx, const float *host_czyx, uint32_t channels)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(host_czyx != nullptr, "null data pointer");
+    REQUIRE(channels == 1 || channels == 4, "channels must be 1 or 4 (got %u)", channels);
+    const size_t bytes = ctx->vox_words * channels * sizeof(float);
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    rc = vrm_check_hip(hipMemcpyAsync(tmp, host_czyx, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    if (!rc) rc = upload_f32_common(ctx, tmp, channels);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int vrm_grid_upload_f32_device(vrm_ctx *ctx, const void *device_czyx, uint32_t channels)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(device_czyx != nullptr, "null data pointer");
+    REQUIRE(channels == 1 || channels == 4, "channels must be 1 or 4 (got %u)", channels);
+    return upload_f32_common(ctx, (const float *)device_czyx, channels);
+}
+
+extern "C" int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, size_t nbytes, uint32_t bytes_per_sample)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(host_raw != nullptr, "null data pointer");
+    REQUIRE(bytes_per_sample == 1 || bytes_per_sample == 2, "bytes_per_sample must be 1 (UCHAR) or 2 (USHORT)");
+    REQUIRE(nbytes == ctx->vox_words * bytes_per_sample, "expected %zu bytes, got %zu", ctx->vox_words * bytes_per_sample, nbytes);
+    uint8_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, nbytes));
+    rc = vrm_check_hip(hipMemcpyAsync(tmp, host_raw, nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    if (!rc) rc = vrm_check_hip(vrm_launch_quantize_scalar(tmp, bytes_per_sample, ctx->vox_words, ctx->vox, ctx->stream), "quantize");
+    if (!rc) rc = grid_finish_upload(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int vrm_grid_download_rgba8(vrm_ctx *ctx, uint8_t *host_voxels, size_t nbytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(host_voxels != nullptr, "null voxel pointer");
+    REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    HIP_TRY(hipMemcpyAsync(host_voxels, ctx->vox, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VRM_OK;
+}
+
+extern "C" int vrm_set_attenuation(vrm_ctx *ctx, float attenuation)
+{
+    REQUIRE(ctx != nullptr, "null context");
+    ctx->attenuation = attenuation;
+    return VRM_OK;
+}
+
+extern "C" int vrm_set_transfer_function(vrm_ctx *ctx, const vrm_transfer_function *tf)
+{
+    REQUIRE(ctx != nullptr && tf != nullptr, "null argument");
+    ctx->tf = *tf;
+    return VRM_OK;
+}
+
+// VoxelGridUniform::new (grid.rs:265-280), f32 arithmetic as written there
+static void grid_uniform(const vrm_ctx *ctx, vrm_grid_uniform *u)
+{
+    uint32_t mn = ctx->dim[0] < ctx->dim[1] ? ctx->dim[0] : ctx->dim[1];
+    if (ctx->dim[2] < mn) mn = ctx->dim[2];
+    for (int i = 0; i < 3; ++i) {
+        u->dimensions[i] = ctx->dim[i];
+        u->box_size[i] = (float)ctx->dim[i] / (float)mn;
+        u->box_min[i] = -u->box_size[i] / 2.0f;
+    }
+    u->dimensions[3] = ctx->dim[0];
+    u->box_size[3] = 0.0f;
+    u->box_min[3] = 0.0f;
+    for (int i = 0; i < 4; ++i) u->buffer[i] = ctx->attenuation;
+}
+
+extern "C" int vrm_get_grid_uniform(vrm_ctx *ctx, vrm_grid_uniform *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+    grid_uniform(ctx, out);
+    return VRM_OK;
+}
+
+// ---- images -------------------------------------------------------------------------------------
+
+extern "C" int vrm_image_create(vrm_ctx *ctx, uint32_t width, uint32_t height, vrm_image **out_image)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(out_image != nullptr, "null argument");
+    *out_image = nullptr;
+    REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
+    vrm_image *img = new (std::nothrow) vrm_image();
+    REQUIRE(img != nullptr, "out of host memory");
+    img->ctx = ctx;
+    img->width = width;
+    img->height = height;
+    img->pitch = (((size_t)width * 4 + 255) / 256) * 256; // screenshot.rs:94-96
+    do {
+        if ((rc = vrm_check_hip(hipMalloc((void **)&img->dev, img->pitch * height), "hipMalloc"))) break;
+        if ((rc = vrm_check_hip(hipHostMalloc((void **)&img->host, img->pitch * height, hipHostMallocDefault), "hipHostMalloc"))) break;
+        if ((rc = vrm_check_hip(hipEventCreateWithFlags(&img->drawn, hipEventDisableTiming), "hipEventCreate"))) break;
+        if ((rc = vrm_check_hip(hipEventCreateWithFlags(&img->copied, hipEventDisableTiming), "hipEventCreate"))) break;
+        // a never-drawn target reads back as the transparent clear colour (mod.rs:124)
+        if ((rc = vrm_check_hip(hipMemsetAsync(img->dev, 0, img->pitch * height, ctx->stream), "hipMemsetAsync"))) break;
+        if ((rc = vrm_check_hip(hipEventRecord(img->drawn, ctx->stream), "hipEventRecord"))) break;
+    } while (0);
+    if (rc) {
+        vrm_image_destroy(img);
+        return rc;
+    }
+    *out_image = img;
+    return VRM_OK;
+}
+
+extern "C" void vrm_image_destroy(vrm_image *img)
+{
+    if (!img) return;
+    if (img->ctx) {
+        (void)hipSetDevice(img->ctx->device);
+        (void)hipStreamSynchronize(img->ctx->stream);
+        (void)hipStreamSynchronize(img->ctx->copy_stream);
+    }
+    if (img->dev) (void)hipFree(img->dev);
+    if (img->host) (void)hipHostFree(img->host);
+    if (img->diag_rgba) (void)hipFree(img->diag_rgba);
+    if (img->diag_iters) (void)hipFree(img->diag_iters);
+    if (img->diag_geom) (void)hipFree(img->diag_geom);
+    if (img->drawn) (void)hipEventDestroy(img->drawn);
+    if (img->copied) (void)hipEventDestroy(img->copied);
+    delete img;
+}
+
+extern "C" int vrm_image_readback_async(vrm_image *img)
+{
+    REQUIRE(img != nullptr, "null image");
+    int rc = bind(img->ctx);
+    if (rc) return rc;
+    if (img->mapped) {
+        vrm_set_error("image is mapped; unmap before the next readback");
+        return VRM_ERR_STATE;
+    }
+    vrm_ctx *ctx = img->ctx;
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, img->drawn, 0));
+    HIP_TRY(hipMemcpyAsync(img->host, img->dev, img->pitch * img->height, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIP_TRY(hipEventRecord(img->copied, ctx->copy_stream));
+    img->copy_pending = true;
+    img->copy_valid = false;
+    return VRM_OK;
+}
+
+extern "C" int vrm_image_map(vrm_image *img, const uint8_t **rgba8, size_t *pitch)
+{
+    REQUIRE(img != nullptr && rgba8 != nullptr && pitch != nullptr, "null argument");
+    int rc = bind(img->ctx);
+    if (rc) return rc;
+    if (img->mapped) {
+        vrm_set_error("image already mapped");
+        return VRM_ERR_STATE;
+    }
+    if (!img->copy_pending && !img->copy_valid) {
+        rc = vrm_image_readback_async(img);
+        if (rc) return rc;
+    }
+    if (img->copy_pending) {
+        HIP_TRY(hipEventSynchronize(img->copied));
+        img->copy_pending = false;
+        img->copy_valid = true;
+    }
+    img->mapped = true;
+    *rgba8 = img->host;
+    *pitch = img->pitch;
+    return VRM_OK;
+}
+
+extern "C" int vrm_image_unmap(vrm_image *img)
+{
+    REQUIRE(img != nullptr, "null image");
+    if (!img->mapped) {
+        vrm_set_error("image is not mapped");
+        return VRM_ERR_STATE;
+    }
+    img->mapped = false;
+    return VRM_OK;
+}
+
+extern "C" int vrm_image_save_png(vrm_image *img, const char *path)
+{
+    REQUIRE(img != nullptr && path != nullptr, "null argument");
+    const uint8_t *px = nullptr;
+    size_t pitch = 0;
+    int rc = vrm_image_map(img, &px, &pitch);
+    if (rc) return rc;
+    rc = vrm_write_png_rgba8(path, px, img->width, img->height, pitch);
+    (void)vrm_image_unmap(img);
+    return rc;
+}
+
+extern "C" int vrm_image_read_ray_diagnostics(vrm_image *img, float *geom8)
+{
+    REQUIRE(img != nullptr && geom8 != nullptr, "null argument");
+    int rc = bind(img->ctx);
+    if (rc) return rc;
+    if (!img->diag_geom) {
+        vrm_set_error("no diagnostics: set VRM_OPT_DIAGNOSTICS before drawing into this image");
+        return VRM_ERR_STATE;
+    }
+    HIP_TRY(hipMemcpyAsync(geom8, img->diag_geom, (size_t)img->width * img->height * 32, hipMemcpyDeviceToHost, img->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(img->ctx->stream));
+    return VRM_OK;
+}
+
+extern "C" int vrm_image_read_diagnostics(vrm_image *img, float *rgba_f32, uint32_t *iterations)
+{
+    REQUIRE(img != nullptr, "null image");
+    int rc = bind(img->ctx);
+    if (rc) return rc;
+    if (!img->diag_rgba || !img->diag_iters) {
+        vrm_set_error("no diagnostics: set VRM_OPT_DIAGNOSTICS before drawing into this image");
+        return VRM_ERR_STATE;
+    }
+    vrm_ctx *ctx = img->ctx;
+    const size_t n = (size_t)img->width * img->height;
+    if (rgba_f32) HIP_TRY(hipMemcpyAsync(rgba_f32, img->diag_rgba, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (iterations) HIP_TRY(hipMemcpyAsync(iterations, img->diag_iters, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VRM_OK;
+}
+
+// ---- draw -----------------------------------------------------------------------------------------
+
+static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint32_t h, size_t pitch)
+{
+    vrm_grid_uniform u;
+    grid_uniform(ctx, &u);
+    VrmGridDev &g = p->grid;
+    g.vox = ctx->vox;
+    g.scalar = ctx->scalar ? 1u : 0u;
+    for (int i = 0; i < 3; ++i) {
+        g.dim[i] = ctx->dim[i];
+        g.box_min[i] = u.box_min[i];
+        g.box_size[i] = u.box_size[i];
+        g.box_max[i] = u.box_min[i] + u.box_size[i]; // wgsl:202,250
+        g.tex_scale[i] = (float)ctx->dim[i] / u.box_size[i];
+        g.tex_bias[i] = -u.box_min[i] * g.tex_scale[i] - 0.5f;
+    }
+    p->width = w;
+    p->height = h;
+    p->pitch_px = (uint32_t)(pitch / 4);
+    p->tiles_x = (w + 15) / 16;
+    p->tiles_y = (h + 15) / 16;
+    p->attenuation = u.buffer[0];
+    for (int i = 0; i < 3; ++i) {
+        p->col_a[i] = ctx->tf.color_a[i];
+        p->col_b[i] = ctx->tf.color_b[i];
+        p->col_c[i] = ctx->tf.color_c[i];
+    }
+    p->use_tf = ctx->tf.use_transfer_function[0] != 0 ? 1u : 0u;
+}
+
+extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(cameras != nullptr && targets != nullptr, "null argument");
+    REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
+    const uint32_t w = targets[0] ? targets[0]->width : 0, h = targets[0] ? targets[0]->height : 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        REQUIRE(targets[i] != nullptr && targets[i]->ctx == ctx, "target %u is null or belongs to another context", i);
+        REQUIRE(targets[i]->width == w && targets[i]->height == h, "all targets of a batch must have the same size");
+        if (targets[i]->mapped) {
+            vrm_set_error("target %u is mapped", i);
+            return VRM_ERR_STATE;
+        }
+    }
+    const bool diag = ctx->opt_diag != 0;
+    if (diag) {
+        for (uint32_t i = 0; i < n; ++i) {
+            vrm_image *img = targets[i];
+            if (!img->diag_rgba) HIP_TRY(hipMalloc((void **)&img->diag_rgba, (size_t)w * h * 16));
+            if (!img->diag_iters) HIP_TRY(hipMalloc((void **)&img->diag_iters, (size_t)w * h * 4));
+            if (!img->diag_geom) HIP_TRY(hipMalloc((void **)&img->diag_geom, (size_t)w * h * 32));
+        }
+    }
+    // descriptor ring: wrap => everything that used the old slots must have finished
+    if (ctx->views_cap + n > kViewRing) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->views_cap = 0;
+    }
+    const uint32_t slot = ctx->views_cap;
+    ctx->views_cap += n;
+    for (uint32_t i = 0; i < n; ++i) {
+        VrmViewDesc &d = ctx->views_host[slot + i];
+        memcpy(d.ivp, cameras[i].inverse_view_proj, 64);
+        memcpy(d.pos, cameras[i].position, 16);
+        d.out = targets[i]->dev;
+        d.diag_rgba = diag ? targets[i]->diag_rgba : nullptr;
+        d.diag_iters = diag ? targets[i]->diag_iters : nullptr;
+        d.diag_geom = diag ? targets[i]->diag_geom : nullptr;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->views_dev + slot, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+
+    VrmMarchParams p;
+    memset(&p, 0, sizeof p);
+    fill_params(ctx, &p, w, h, targets[0]->pitch);
+    p.views = ctx->views_dev + slot;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->opt_profile) {
+        if (ctx->prof_used == ctx->prof_events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            ctx->prof_events.emplace_back(a, b);
+        }
+        e0 = ctx->prof_events[ctx->prof_used].first;
+        e1 = ctx->prof_events[ctx->prof_used].second;
+        ctx->prof_used++;
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, diag, ctx->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        vrm_image *img = targets[i];
+        HIP_TRY(hipEventRecord(img->drawn, ctx->stream));
+        img->has_draw = true;
+        img->copy_valid = false;
+        img->copy_pending = false;
+    }
+    return VRM_OK;
+}
+
+extern "C" int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *target)
+{
+    return vrm_draw_batch(ctx, camera, 1, &target);
+}
+
+extern "C" int vrm_synchronize(vrm_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+    return VRM_OK;
+}
+
+// ---- options / profiling ------------------------------------------------------------------------
+
+extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
+{
+    REQUIRE(ctx != nullptr, "null context");
+    switch (option) {
+    case VRM_OPT_KERNEL: ctx->opt_kernel = value; break;
+    case VRM_OPT_SKIP_EMPTY: ctx->opt_skip = value; break;
+    case VRM_OPT_PROFILE: ctx->opt_profile = value; break;
+    case VRM_OPT_DIAGNOSTICS: ctx->opt_diag = value; break;
+    default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
+    }
+    return VRM_OK;
+}
+
+extern "C" int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value)
+{
+    REQUIRE(ctx != nullptr && value != nullptr, "null argument");
+    switch (option) {
+    case VRM_OPT_KERNEL: *value = ctx->opt_kernel; break;
+    case VRM_OPT_SKIP_EMPTY: *value = ctx->opt_skip; break;
+    case VRM_OPT_PROFILE: *value = ctx->opt_profile; break;
+    case VRM_OPT_DIAGNOSTICS: *value = ctx->opt_diag; break;
+    default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
+    }
+    return VRM_OK;
+}
+
+extern "C" int vrm_profile_read(vrm_ctx *ctx, double *kernel_ms, uint64_t *launches, int reset)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second));
+        ctx->prof_ms += ms;
+        ctx->prof_launches++;
+    }
+    ctx->prof_used = 0;
+    if (kernel_ms) *kernel_ms = ctx->prof_ms;
+    if (launches) *launches = ctx->prof_launches;
+    if (reset) {
+        ctx->prof_ms = 0.0;
+        ctx->prof_launches = 0;
+    }
+    return VRM_OK;
+}

@@ -1,0 +1,49 @@
+// vrm_device.h -- structs shared between the C-ABI host code (vrm_api.cpp) and the HIP kernels
+// (vrm_kernels.hip).  Internal; the public contract is include/vrm.h.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define VRM_MAX_STEP_AMOUNT 5000 /* raymarcher.wgsl:96 */
+#define VRM_STEP_SIZE 0.001f     /* raymarcher.wgsl:126 */
+
+// One entry per view of a batch, resident in device memory (read through the scalar cache).
+struct VrmViewDesc {
+    float ivp[16];       // CameraUniform.inverse_view_proj, column-major (camera.rs:48)
+    float pos[4];        // CameraUniform.position
+    uint32_t *out;       // RGBA8 target, row pitch = VrmMarchParams.pitch_px words
+    float *diag_rgba;    // optional W*H*4 f32 (VRM_OPT_DIAGNOSTICS)
+    uint32_t *diag_iters; // optional W*H u32
+    float *diag_geom;     // optional W*H*8 f32: rd.xyz, t_min, t_max, #samples inside the box, hit, 0
+};
+
+// Volume as the kernels see it.
+struct VrmGridDev {
+    const uint32_t *vox; // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211)
+    uint32_t dim[3];
+    uint32_t scalar;     // 1 => every voxel has r == g == b == a (DAT volumes, dat.rs:74)
+    float box_min[3];    // VoxelGridUniform.box_min (grid.rs:271)
+    float box_max[3];    // box_min + box_size, rounded as the shader computes it (wgsl:202,250)
+    float box_size[3];
+    float tex_scale[3];  // dim / box_size
+    float tex_bias[3];   // -box_min*tex_scale - 0.5
+};
+
+struct VrmMarchParams {
+    VrmGridDev grid;
+    const VrmViewDesc *views;
+    uint32_t width, height, pitch_px;
+    uint32_t tiles_x, tiles_y;
+    float attenuation;   // voxel_grid.buffer[0] (wgsl:150)
+    float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
+    uint32_t use_tf;
+};
+
+// launchers implemented in vrm_kernels.hip
+hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, hipStream_t stream);
+hipError_t vrm_launch_quantize_f32(const float *src_czyx, uint32_t channels, size_t n_voxels, uint32_t *dst, hipStream_t stream);
+hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sample, size_t n_voxels, uint32_t *dst,
+                                      hipStream_t stream);
+hipError_t vrm_launch_fill(uint32_t *dst, size_t n_words, uint32_t value, hipStream_t stream);
+// sets *flag_dev to 1 if some voxel has r,g,b not all equal to a (i.e. the grid is not "scalar")
+hipError_t vrm_launch_detect_nonscalar(const uint32_t *vox, size_t n_voxels, uint32_t *flag_dev, hipStream_t stream);

@@ -1,0 +1,58 @@
+// vrm_internal.h -- host-side objects behind the opaque handles of include/vrm.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/vrm.h"
+#include "vrm_device.h"
+
+struct vrm_ctx {
+    int device = 0;
+    uint32_t def_width = 0, def_height = 0;
+    hipStream_t stream = nullptr;      // every kernel of this context is launched here
+    hipStream_t copy_stream = nullptr; // device->host readbacks, ordered behind draws by events
+
+    // VoxelGrid (voxel/grid.rs:9-22)
+    uint32_t dim[3] = {0, 0, 0};
+    uint32_t *vox = nullptr; // RGBA8 words, x fastest
+    size_t vox_words = 0;
+    bool scalar = false;     // r == g == b == a everywhere
+    float attenuation = 1.0f;
+    vrm_transfer_function tf;
+    uint32_t *flag_dev = nullptr; // 1 word scratch for detect_nonscalar
+
+    // batch descriptors (device + pinned staging)
+    VrmViewDesc *views_dev = nullptr;
+    VrmViewDesc *views_host = nullptr; // pinned
+    uint32_t views_cap = 0;
+    hipEvent_t views_free = nullptr;   // signalled when the last batch's descriptor upload was consumed
+
+    // options
+    int64_t opt_kernel = 0, opt_skip = 0, opt_profile = 0, opt_diag = 0;
+
+    // profiling (VRM_OPT_PROFILE)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0;
+};
+
+struct vrm_image {
+    vrm_ctx *ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    size_t pitch = 0;            // bytes, ceil(4w/256)*256 (screenshot.rs:94-96)
+    uint32_t *dev = nullptr;     // render target
+    uint8_t *host = nullptr;     // pinned readback buffer (the MAP_READ buffer of screenshot.rs:16-22)
+    float *diag_rgba = nullptr;  // lazily allocated with VRM_OPT_DIAGNOSTICS
+    uint32_t *diag_iters = nullptr;
+    float *diag_geom = nullptr;
+    hipEvent_t drawn = nullptr;  // recorded on ctx->stream after the last draw into this image
+    hipEvent_t copied = nullptr; // recorded on ctx->copy_stream after the last readback
+    bool has_draw = false, copy_pending = false, copy_valid = false, mapped = false;
+};
+
+void vrm_set_error(const char *fmt, ...);
+int vrm_check_hip(hipError_t e, const char *what);
+
+// host helpers implemented in vrm_host.cpp
+int vrm_write_png_rgba8(const char *path, const uint8_t *rgba, uint32_t w, uint32_t h, size_t pitch);
