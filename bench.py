@@ -1,0 +1,198 @@
+"""bench.py -- the headline benchmark of the ray-marching path (BASELINE.json configs[2]):
+512^3 float32 NetCDF-style volume (DiffDVR layout, quantised to RGBA8 on ingest exactly as
+loaders/netcdf.rs does), 256-view sphere export at 1024^2, view-partitioned over N GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over the whole 256-view export (ray march of every view + the
+asynchronous read-back of every image to pinned host memory).  Rank r renders views i with
+i % N == r; the only collective is one RCCL broadcast of the volume before the timed region (reported
+as volume_broadcast_ms).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dim", type=int, default=512, help="volume edge (C3: 512)")
+    ap.add_argument("--res", type=int, default=1024, help="image edge (C3: 1024)")
+    ap.add_argument("--xdiv", type=int, default=16)
+    ap.add_argument("--ydiv", type=int, default=17, help="views = xdiv*(ydiv-1) (C3: 16*16 = 256)")
+    ap.add_argument("--radius", type=float, default=2.5)
+    ap.add_argument("--attenuation", type=float, default=1.0)
+    ap.add_argument("--tf", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=32, help="views per launch")
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--skip-empty", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-res", type=int, default=384, help="image edge of the bounded CPU-baseline sample")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: the HIP library then shares torch's libamdhip64 instead of loading a second runtime
+
+    import volume_renderer_amd as vr
+    from volume_renderer_amd import distributed as vd
+    from volume_renderer_amd import synth
+
+    rank, local_rank, world = vd.env_rank()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-marching path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        vd.init_process_group("nccl")
+
+    D, R = a.dim, a.res
+    dims = (D, D, D)
+    rm = vr.RayMarcher(local_rank, R, R)
+    rm.set_option(vr.OPT_KERNEL, a.kernel)
+    rm.set_option(vr.OPT_SKIP_EMPTY, a.skip_empty)
+
+    # ---- volume: rank 0 builds it, one RCCL broadcast, every rank ingests from device memory -----------
+    t0 = time.time()
+    host_q = None
+    if rank == 0:
+        host_q = synth.quantize_rgba8(synth.blobs_rgba_f32(dims))  # (v*255.0) as u8, loaders/netcdf.rs:54-57
+        vol = torch.from_numpy(host_q).to(dev)
+    else:
+        vol = torch.empty((D, D, D, 4), dtype=torch.uint8, device=dev)
+    gen_s = time.time() - t0
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    vd.broadcast_volume(vol, src=0)
+    torch.cuda.synchronize()
+    bcast_ms = (time.time() - t0) * 1e3 if world > 1 else 0.0
+    rm.voxel_grid.new(dims)
+    rm.voxel_grid.upload_rgba8_device(vol.data_ptr(), vol.numel())
+    rm.voxel_grid.attenuation = a.attenuation
+    rm.voxel_grid.update_voxel_grid_buffer()
+    rm.voxel_grid.set_transfer_function_active(bool(a.tf))
+    rm.voxel_grid.update_transfer_function_buffer()
+    del vol
+    torch.cuda.empty_cache()
+
+    # ---- view list (sphere_screenshot_manager.rs order), interleaved partition ------------------------
+    cam = vr.Camera(1.0)
+    csp = vr.CameraSphereController(a.ydiv, a.xdiv, (0.0, 0.0, 0.0), a.radius)
+    cams = []
+    for ix, iy in vr.sphere_views(a.xdiv, a.ydiv):
+        csp.current_index_x, csp.current_index_y = ix, iy
+        csp.update_position(cam)
+        cams.append(cam.uniform())
+    n_views = len(cams)
+    mine = vd.partition_views(n_views, rank, world)
+    my_cams = [cams[i] for i in mine]
+    B = max(1, min(a.batch, len(my_cams)))
+    banks = [[vr.Screenshotter(rm, R, R) for _ in range(B)] for _ in range(2)]
+
+    def step():
+        which = 0
+        for c0 in range(0, len(my_cams), B):
+            chunk = my_cams[c0:c0 + B]
+            imgs = banks[which][:len(chunk)]
+            for im in imgs:          # this bank's previous read-back must have landed before it is redrawn
+                im.wait()
+            rm.draw_batch(chunk, imgs)
+            for im in imgs:
+                im.screenshot()      # async device->host copy behind the draw
+            which ^= 1
+
+    n_ref_mine = rm.count_reference_samples(my_cams, R, R) if my_cams else 0
+
+    for _ in range(a.warmup):
+        step()
+    rm.synchronize()
+    rm.set_option(vr.OPT_PROFILE, 1)
+    rm.profile_read()
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    rm.synchronize()             # compute stream and copy stream of the library
+    torch.cuda.synchronize()
+    vd.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = vd.max_over_ranks(elapsed, dev)
+    kernel_ms, launches = rm.profile_read()
+    rm.set_option(vr.OPT_PROFILE, 0)
+    n_ref = vd.sum_over_ranks(n_ref_mine, dev)
+
+    views_per_s = n_views * a.steps / elapsed
+    gsamples = n_ref * a.steps / elapsed / 1e9
+
+    # ---- roofline of the march kernel on this rank: algorithmic bytes = every voxel read once (4 B, the
+    # reference's own texel format) + every RGBA8 pixel written once, per view -------------
+    b_alg_view = D * D * D * 4 + R * R * 4
+    views_timed = len(my_cams) * a.steps
+    achieved = (b_alg_view * views_timed / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "march kernel (variant %d)" % a.kernel, "launches": int(launches),
+                "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
+                "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B}
+
+    out = {
+        "metric": "views/s", "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C3: {D}^3 float32 RGBA volume (blobs seed {synth.DEFAULT_SEED}, quantised to RGBA8 on ingest), "
+                               f"{n_views}-view sphere export at {R}x{R}, radius {a.radius}, attenuation {a.attenuation}, "
+                               f"transfer function {'on' if a.tf else 'off'}",
+                   "volume": [D, D, D], "image": [R, R], "views": n_views, "parallelism": f"view-partitioned x{world}",
+                   "kernel_variant": a.kernel, "skip_empty": a.skip_empty},
+        "gsamples_per_s": round(gsamples, 3), "reference_samples_per_step": int(n_ref),
+        "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
+        "volume_broadcast_ms": round(bcast_ms, 2), "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle ("port"; the wgpu reference cannot run here) on a bounded sample -------
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        import oracle
+        threads = max(1, min(16, os.cpu_count() or 1))
+        r = a.cpu_res
+        mid = n_views // 2 + a.xdiv // 4
+        ix, iy = vr.sphere_views(a.xdiv, a.ydiv)[mid]
+        cam36 = oracle.camera_uniform(oracle.sphere_position(ix, iy, a.xdiv, a.ydiv, a.radius))
+        t0 = time.perf_counter()
+        res = oracle.render(host_q, cam36, r, r, attenuation=a.attenuation, tf=oracle.tf_words(bool(a.tf)), want_f32=False,
+                            threads=threads)
+        cpu_s = time.perf_counter() - t0
+        cpu_samples_per_s = res["samples"] / cpu_s
+        out["cpu_baseline"] = {
+            "value": round(cpu_samples_per_s / (n_ref / n_views), 4), "unit": "views/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/vr_oracle.c (CPU restatement, not the wgpu reference), view {ix}-{iy} of the same volume at "
+                      f"{r}x{r} ({res['samples']} samples in {cpu_s:.2f} s), scaled to views/s by the mean samples per {R}x{R} view",
+            "gsamples_per_s": round(cpu_samples_per_s / 1e9, 5),
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    for bank in banks:
+        for im in bank:
+            im.close()
+    rm.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,13 @@ VRM_API int vrm_image_read_diagnostics(vrm_image *image, float *rgba_f32, uint32
  * in-box test (wgsl:218-223), hit flag (wgsl:131), 0 -- so tests can check the geometry bit for bit. */
 VRM_API int vrm_image_read_ray_diagnostics(vrm_image *image, float *geom8);
 
+/* Reference-equivalent sample count (the unit of the Gsamples/s metric): the number of
+ * iterations the loop of raymarch() (raymarcher.wgsl:139-187) executes, summed over all rays of the n
+ * views at width x height, for the current grid's box -- pure geometry on the reference's dt lattice,
+ * without the `alpha >= 1.0` exit (which cannot fire while a*attenuation*0.001 < ln 2). */
+VRM_API int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, uint32_t width,
+                                        uint32_t height, uint64_t *out_total);
+
 VRM_API const char *vrm_last_error(void);
 VRM_API const char *vrm_version(void);
 

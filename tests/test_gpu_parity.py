@@ -1,0 +1,186 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same seeded inputs.
+
+Gate (BASELINE.md section 2 / north_star): max |delta| <= 1/255 per RGBA channel on the 8-bit image and
+normalised RMSE (scripts/similarity.py:59-62, /255) < 1e-3.  On top of that the f32 accumulators agree
+to 1e-4 and the ray geometry (direction, t_min, t_max, iteration count, in-box sample count) is required
+to be BIT-EXACT, because it drives the discontinuous decisions of the shader."""
+import numpy as np
+import pytest
+
+from conftest import image_metrics, sphere_cam
+from volume_renderer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+
+
+def configure(rm, vox, att=1.0, use_tf=False):
+    g = rm.voxel_grid
+    g.upload_rgba8(vox)
+    g.attenuation = att
+    g.update_voxel_grid_buffer()
+    g.set_transfer_function_active(use_tf)
+    g.update_transfer_function_buffer()
+
+
+def draw(rm, vr, cam36, W, H, diag=True):
+    rm.set_option(vr.OPT_DIAGNOSTICS, 1 if diag else 0)
+    img = vr.Screenshotter(rm, W, H)
+    rm.draw(vr.uniform_from_array(cam36), img)
+    out = {"rgba8": img.read()}
+    if diag:
+        out["f32"], out["iters"] = img.diagnostics()
+        out["geo"] = img.ray_diagnostics()
+    img.close()
+    rm.set_option(vr.OPT_DIAGNOSTICS, 0)
+    return out
+
+
+def check(orc, got, vox, cam, W, H, att, use_tf, ert_free=True):
+    ref = orc.render(vox, cam, W, H, attenuation=att, tf=orc.tf_words(use_tf), want_steps=True)
+    m = image_metrics(got["rgba8"], ref["rgba8"])
+    assert m["max"] <= 1, m
+    assert m["rmse_norm"] < 1e-3, m
+    assert np.abs(got["f32"] - ref["f32"]).max() < F32_TOL
+    assert np.array_equal(got["iters"], ref["steps"])
+    Z, Y, X, _ = vox.shape
+    geo = orc.geometry(cam, (X, Y, Z), W, H)
+    cols = [0, 1, 2, 3, 4, 6, 7] + ([5] if ert_free else [])
+    for k in cols:
+        assert np.array_equal(got["geo"][..., k].view(np.uint32), geo[..., k].view(np.uint32)), f"geometry column {k}"
+    return m
+
+
+VOLUMES = {
+    "blobs_rgba": lambda: synth.quantize_rgba8(synth.blobs_rgba_f32((48, 40, 32))),
+    "blobs_scalar": lambda: np.repeat(synth.blobs_scalar_u8((64, 64, 64))[..., None], 4, 3),
+    "random_noncubic": lambda: synth.random_rgba8((17, 9, 33), 7),
+    "solid_200": lambda: synth.solid_rgba8((8, 8, 8), 200),
+}
+
+
+@pytest.mark.parametrize("vol", sorted(VOLUMES))
+@pytest.mark.parametrize("att,use_tf", [(1.0, False), (20.0, False), (1.0, True), (100.0, True)])
+def test_parity_matrix(rm, vr, orc, vol, att, use_tf):
+    vox = VOLUMES[vol]()
+    configure(rm, vox, att, use_tf)
+    for ix, iy in [(1, 3), (6, 6)]:
+        cam = sphere_cam(orc, ix, iy)
+        got = draw(rm, vr, cam, 96, 80)
+        check(orc, got, vox, cam, 96, 80, att, use_tf)
+
+
+def test_parity_all_views_of_default_sphere(rm, vr, orc):
+    """the 8x8 export (56 views, similarity.py:51-55) at low resolution, averaged like similarity.py:75-78"""
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((32, 32, 32)))
+    configure(rm, vox, 4.0, False)
+    tot_rmse, worst = 0.0, 0
+    views = orc.sphere_views(8, 8)
+    for ix, iy in views:
+        cam = sphere_cam(orc, ix, iy)
+        got = draw(rm, vr, cam, 48, 48)
+        m = check(orc, got, vox, cam, 48, 48, 4.0, False)
+        tot_rmse += m["rmse_norm"]
+        worst = max(worst, m["max"])
+    assert worst <= 1 and tot_rmse / len(views) < 1e-3
+
+
+def test_parity_ragged_image_sizes(rm, vr, orc):
+    """sizes that are not multiples of the 16x16 workgroup tile or the 8x8 wave tile, incl. 1x1"""
+    vox = synth.random_rgba8((12, 10, 14), 1)
+    configure(rm, vox, 10.0, False)
+    for W, H in [(1, 1), (7, 5), (50, 37), (65, 16), (16, 65), (130, 3)]:
+        cam = sphere_cam(orc, 2, 5, aspect=W / H)
+        got = draw(rm, vr, cam, W, H)
+        check(orc, got, vox, cam, W, H, 10.0, False)
+
+
+def test_parity_degenerate_volumes(rm, vr, orc):
+    for dims in [(1, 1, 1), (2, 1, 1), (1, 5, 1), (3, 3, 3), (64, 2, 2), (2, 2, 64)]:
+        vox = synth.random_rgba8(dims, 3)
+        configure(rm, vox, 50.0, False)
+        cam = sphere_cam(orc, 5, 3, radius=max(dims) / min(dims) * 1.2 + 1.5)
+        got = draw(rm, vr, cam, 40, 40)
+        check(orc, got, vox, cam, 40, 40, 50.0, False)
+
+
+def test_parity_camera_inside_volume(rm, vr, orc):
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((24, 24, 24)))
+    configure(rm, vox, 5.0, True)
+    cam = orc.camera_uniform(np.array([0.1, 0.2, 0.3], np.float32), target=(1.0, 0.5, 0.0))
+    got = draw(rm, vr, cam, 64, 64)
+    check(orc, got, vox, cam, 64, 64, 5.0, True)
+    assert (got["geo"][..., 3] < 0).all()  # negative t_min is kept (wgsl:137)
+
+
+def test_parity_axis_aligned_rays_with_zero_direction_components(rm, vr, orc):
+    vox = synth.random_rgba8((6, 6, 6), 5)
+    configure(rm, vox, 20.0, False)
+    cam = orc.camera_uniform(np.array([0.0, 0.0, 0.2], np.float32), target=(0.0, 0.0, -1.0))
+    got = draw(rm, vr, cam, 15, 15)
+    check(orc, got, vox, cam, 15, 15, 20.0, False)
+
+
+def test_parity_reference_default_radius_100(rm, vr, orc):
+    vox = synth.random_rgba8((8, 8, 8), 2)
+    configure(rm, vox, 5.0, True)
+    cam = sphere_cam(orc, 2, 5, radius=100.0)
+    got = draw(rm, vr, cam, 512, 512)
+    check(orc, got, vox, cam, 512, 512, 5.0, True)
+    assert 10 < (got["rgba8"][..., 3] > 0).sum() < 2000
+
+
+def test_early_termination_matches_oracle(rm, vr, orc):
+    """alpha >= 1.0 (wgsl:176-178) only fires when one step closes the gap: attenuation 1000."""
+    vox = synth.solid_rgba8((4, 4, 4), 255)
+    configure(rm, vox, 1000.0, False)
+    cam = sphere_cam(orc, 1, 3)
+    got = draw(rm, vr, cam, 32, 32)
+    ref = orc.render(vox, cam, 32, 32, attenuation=1000.0, want_steps=True)
+    full = orc.geometry(cam, (4, 4, 4), 32, 32)[..., 7]
+    assert (ref["steps"][full > 100] < 40).all()
+    assert np.abs(got["iters"].astype(int) - ref["steps"].astype(int)).max() <= 1  # rounding of the last step to 1.0
+    assert image_metrics(got["rgba8"], ref["rgba8"])["max"] <= 1
+
+
+def test_closed_form_homogeneous_on_gpu(rm, vr, orc):
+    for val, att in [(128, 1.0), (40, 7.5)]:
+        vox = synth.solid_rgba8((8, 8, 8), val)
+        configure(rm, vox, att, False)
+        cam = sphere_cam(orc, 1, 3)
+        got = draw(rm, vr, cam, 48, 48)
+        n = got["geo"][..., 5].astype(np.float64)
+        want = 1.0 - np.exp(-(val / 255.0) * att * 0.001 * n)
+        assert np.abs(got["f32"][..., 3] - want).max() < 1e-4
+        assert np.abs(got["f32"][..., 0] - (val / 255.0) * want).max() < 1e-4
+
+
+def test_scalar_and_rgba_filters_agree(rm, vr, orc):
+    """a DAT-style volume (r=g=b=a) takes the 1-channel filter; perturbing one voxel's red forces the 4-channel
+    one; away from that voxel the two images must be identical."""
+    s = synth.blobs_scalar_u8((32, 32, 32))
+    vox = np.repeat(s[..., None], 4, 3)
+    cam = sphere_cam(orc, 3, 4)
+    configure(rm, vox, 3.0, False)
+    a = draw(rm, vr, cam, 64, 64)
+    vox2 = vox.copy()
+    vox2[0, 0, 0, 0] ^= 1
+    configure(rm, vox2, 3.0, False)
+    b = draw(rm, vr, cam, 64, 64)
+    assert (a["rgba8"] != b["rgba8"]).sum() <= 8
+    assert np.abs(a["f32"] - b["f32"]).max() < 1e-5
+
+
+def test_batch_equals_single_draws(rm, vr, orc):
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((32, 24, 40)))
+    configure(rm, vox, 2.0, False)
+    cams = [vr.uniform_from_array(sphere_cam(orc, ix, iy)) for ix, iy in [(0, 1), (3, 3), (7, 6), (4, 2), (1, 5)]]
+    imgs = [vr.Screenshotter(rm, 80, 64) for _ in cams]
+    rm.draw_batch(cams, imgs)
+    batch = [im.read() for im in imgs]
+    for cam, im, want in zip(cams, imgs, batch):
+        rm.draw(cam, im)
+        assert np.array_equal(im.read(), want)
+    for im in imgs:
+        im.close()

@@ -152,7 +152,8 @@ class VoxelGrid:
         _ffi.check(_ffi.lib().vrm_grid_upload_scalar(self._rm._h, r.ctypes.data, r.nbytes, bytes_per_sample))
 
     def download_rgba8(self):
-        x, y, z = self.dimensions
+        x, y, z = (int(d) for d in self.uniform().dimensions[:3])
+        self.dimensions = (x, y, z)
         out = np.zeros((z, y, x, 4), dtype=np.uint8)
         _ffi.check(_ffi.lib().vrm_grid_download_rgba8(self._rm._h, out.ctypes.data, out.nbytes))
         return out
@@ -211,6 +212,13 @@ class Screenshotter:
             _ffi.check(_ffi.lib().vrm_image_unmap(self._h))
         return out
 
+    def wait(self):
+        """map + unmap without copying out: returns once the last readback has landed in host memory."""
+        p = ctypes.POINTER(ctypes.c_uint8)()
+        pitch = ctypes.c_size_t()
+        _ffi.check(_ffi.lib().vrm_image_map(self._h, ctypes.byref(p), ctypes.byref(pitch)))
+        _ffi.check(_ffi.lib().vrm_image_unmap(self._h))
+
     def save_screenshot_to_disk(self, file_name):
         """screenshot.rs:57-92."""
         _ffi.check(_ffi.lib().vrm_image_save_png(self._h, os.fsencode(file_name)))
@@ -260,6 +268,14 @@ class RayMarcher:
         cams = (CameraUniform * n)(*camera_uniforms)
         hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
         _ffi.check(_ffi.lib().vrm_draw_batch(self._h, cams, n, hs))
+
+    def count_reference_samples(self, camera_uniforms, width, height):
+        """loop iterations the reference would execute for these views (unit of Gsamples/s)."""
+        n = len(camera_uniforms)
+        cams = (CameraUniform * n)(*camera_uniforms)
+        total = ctypes.c_uint64()
+        _ffi.check(_ffi.lib().vrm_count_reference_samples(self._h, cams, n, int(width), int(height), ctypes.byref(total)))
+        return total.value
 
     def synchronize(self):
         _ffi.check(_ffi.lib().vrm_synchronize(self._h))

@@ -528,6 +528,41 @@ extern "C" int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_imag
     return vrm_draw_batch(ctx, camera, 1, &target);
 }
 
+extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, uint32_t width,
+                                           uint32_t height, uint64_t *out_total)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(cameras != nullptr && out_total != nullptr, "null argument");
+    REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
+    REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
+    if (ctx->views_cap + n > kViewRing) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->views_cap = 0;
+    }
+    const uint32_t slot = ctx->views_cap;
+    ctx->views_cap += n;
+    for (uint32_t i = 0; i < n; ++i) {
+        VrmViewDesc &d = ctx->views_host[slot + i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.ivp, cameras[i].inverse_view_proj, 64);
+        memcpy(d.pos, cameras[i].position, 16);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->views_dev + slot, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    VrmMarchParams p;
+    memset(&p, 0, sizeof p);
+    fill_params(ctx, &p, width, height, (size_t)width * 4);
+    p.views = ctx->views_dev + slot;
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(ctx->flag_dev + 2); // 8-byte aligned word of the 256 B scratch
+    HIP_TRY(hipMemsetAsync(cnt, 0, 8, ctx->stream));
+    HIP_TRY(vrm_launch_count_samples(p, n, cnt, ctx->stream));
+    unsigned long long host = 0;
+    HIP_TRY(hipMemcpyAsync(&host, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out_total = host;
+    return VRM_OK;
+}
+
 extern "C" int vrm_synchronize(vrm_ctx *ctx)
 {
     int rc = bind(ctx);

@@ -41,6 +41,7 @@ struct VrmMarchParams {
 
 // launchers implemented in vrm_kernels.hip
 hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, hipStream_t stream);
+hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream);
 hipError_t vrm_launch_quantize_f32(const float *src_czyx, uint32_t channels, size_t n_voxels, uint32_t *dst, hipStream_t stream);
 hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sample, size_t n_voxels, uint32_t *dst,
                                       hipStream_t stream);

@@ -199,6 +199,38 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Reference-equivalent sample count: the number of loop iterations raymarch() (wgsl:139-187) executes
+// for every ray of a view when the early exit `alpha >= 1.0` does not fire (it cannot for
+// a*attenuation*0.001 < ln 2).  Pure geometry: the same dt lattice, no sampling.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) count_samples_kernel(const VrmMarchParams P, unsigned long long *total)
+{
+    const VrmGridDev &g = P.grid;
+    const uint32_t view = blockIdx.y;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t px = tx * TILE + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = ty * TILE + (wave >> 1) * 8u + (lane >> 3);
+    unsigned long long n = 0;
+    if (px < P.width && py < P.height) {
+        const Ray ray = setup_ray(P.views[view], g, px, py, P.width, P.height);
+        if (ray.hit) {
+            float dt = ray.t_min;
+            for (int i = 0; i < VRM_MAX_STEP_AMOUNT; ++i) {
+                ++n;
+                dt += VRM_STEP_SIZE;
+                if (dt >= ray.t_max) break;
+            }
+        }
+    }
+    // wave reduction, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if (lane == 0 && n) atomicAdd(total, n);
+}
+
+// ---------------------------------------------------------------------------------------------
 // ingest kernels (HBM-bound, trivially parallel)
 // ---------------------------------------------------------------------------------------------
 
@@ -293,6 +325,12 @@ hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int varia
         else VRM_LAUNCH(false, false, false);
     }
 #undef VRM_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(count_samples_kernel, dim3(p.tiles_x * p.tiles_y, n_views, 1), dim3(256, 1, 1), 0, stream, p, total_dev);
     return hipGetLastError();
 }
 
