@@ -33,12 +33,17 @@ def vr():
     return volume_renderer_amd
 
 
-@pytest.fixture()
-def rm(vr):
-    """A fresh RayMarcher on GPU 0.  GPU tests fail loudly if the HIP library or the device is missing."""
+KERNEL_VARIANTS = [0, 1]  # 0: global gathers (baseline), 1: per-wave LDS staging (default)
+
+
+@pytest.fixture(params=KERNEL_VARIANTS, ids=[f"k{k}" for k in KERNEL_VARIANTS])
+def rm(vr, request):
+    """A fresh RayMarcher on GPU 0, once per kernel variant.  GPU tests fail loudly if the HIP library or the
+    device is missing."""
     if not have_gpu():
         pytest.skip("no /dev/kfd: GPU tests only run on the GPU box (-m gpu)")
     r = vr.RayMarcher(0, 256, 256)
+    r.set_option(vr.OPT_KERNEL, request.param)
     yield r
     r.close()
 

@@ -1,0 +1,63 @@
+"""Small fixed workload for rocprofv3 passes: N views of the C3 volume with one kernel variant.
+
+usage: python tools/prof_workload.py [--kernel K] [--views N] [--dim D] [--res R] [--reps M] [--scalar] [--tf]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import volume_renderer_amd as vr  # noqa: E402
+from volume_renderer_amd import synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", type=int, default=1)
+    ap.add_argument("--skip", type=int, default=0)
+    ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--scalar", action="store_true")
+    ap.add_argument("--tf", action="store_true")
+    ap.add_argument("--att", type=float, default=1.0)
+    a = ap.parse_args()
+    D, R = a.dim, a.res
+    rm = vr.RayMarcher(0, R, R)
+    rm.set_option(vr.OPT_KERNEL, a.kernel)
+    rm.set_option(vr.OPT_SKIP_EMPTY, a.skip)
+    if a.scalar:
+        s = synth.blobs_scalar_u8((D, D, D))
+        rm.voxel_grid.upload_scalar(s.reshape(-1), (D, D, D), 1)
+    else:
+        rm.voxel_grid.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32((D, D, D))))
+    rm.voxel_grid.attenuation = a.att
+    rm.voxel_grid.update_voxel_grid_buffer()
+    rm.voxel_grid.set_transfer_function_active(a.tf)
+    rm.voxel_grid.update_transfer_function_buffer()
+    allv = vr.sphere_views(16, 17)
+    views = allv[:: max(1, len(allv) // a.views)][: a.views]
+    cam = vr.Camera(1.0)
+    csp = vr.CameraSphereController(17, 16, (0, 0, 0), 2.5)
+    cams = []
+    for ix, iy in views:
+        csp.current_index_x, csp.current_index_y = ix, iy
+        csp.update_position(cam)
+        cams.append(cam.uniform())
+    imgs = [vr.Screenshotter(rm, R, R) for _ in cams]
+    n_ref = rm.count_reference_samples(cams, R, R)
+    rm.set_option(vr.OPT_PROFILE, 1)
+    for rep in range(a.reps):
+        rm.draw_batch(cams, imgs)
+        rm.synchronize()
+        ms, n = rm.profile_read()
+        print(f"kernel {a.kernel} skip {a.skip}: {len(cams)} views {R}^2 of {D}^3: {ms:.2f} ms => {ms / len(cams):.3f} ms/view, "
+              f"{n_ref / ms / 1e6:.1f} Gsamples/s (ref-equivalent)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -442,6 +442,8 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     p->pitch_px = (uint32_t)(pitch / 4);
     p->tiles_x = (w + 15) / 16;
     p->tiles_y = (h + 15) / 16;
+    p->sblocks_x = (((w + 63) / 64) + 7u) & ~7u; // 64x64-pixel super-blocks, columns padded to a multiple of 8 (XCD diagonals)
+    p->sblocks_y = (h + 63) / 64;
     p->attenuation = u.buffer[0];
     for (int i = 0; i < 3; ++i) {
         p->col_a[i] = ctx->tf.color_a[i];

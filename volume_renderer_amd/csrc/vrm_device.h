@@ -33,7 +33,8 @@ struct VrmMarchParams {
     VrmGridDev grid;
     const VrmViewDesc *views;
     uint32_t width, height, pitch_px;
-    uint32_t tiles_x, tiles_y;
+    uint32_t tiles_x, tiles_y;     // 16x16-pixel workgroup tiles (variant 0)
+    uint32_t sblocks_x, sblocks_y; // 64x64-pixel super-blocks of 8x8-pixel wave tiles (variant 1); x padded to a multiple of 8
     float attenuation;   // voxel_grid.buffer[0] (wgsl:150)
     float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
     uint32_t use_tf;

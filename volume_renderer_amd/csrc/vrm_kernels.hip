@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int TILE = 16;        // workgroup = 16x16 pixels = 4 waves, each wave an 8x8 pixel tile
+constexpr int TILE = 16;        // variant 0: workgroup = 16x16 pixels = 4 waves, each wave an 8x8 pixel tile
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each XCD a
@@ -36,6 +36,8 @@ struct Ray {
 };
 
 // fs_main (wgsl:98-108) + aabb_intersect (wgsl:247-299); op-for-op the oracle's shade_pixel().
+// sqrtf and '/' are the correctly rounded forms (-fhip-fp32-correctly-rounded-divide-sqrt); the
+// __fsqrt_rn intrinsic is NOT correctly rounded on gfx950 (tools/probes/fp_probe.hip).
 __device__ __forceinline__ Ray setup_ray(const VrmViewDesc &v, const VrmGridDev &g, uint32_t px, uint32_t py, uint32_t W,
                                          uint32_t H)
 {
@@ -49,20 +51,20 @@ __device__ __forceinline__ Ray setup_ray(const VrmViewDesc &v, const VrmGridDev 
     const float len = __builtin_sqrtf((w3[0] * w3[0] + w3[1] * w3[1]) + w3[2] * w3[2]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        r.rd[k] = ((w3[k]) / (len));
+        r.rd[k] = w3[k] / len;
         r.ro[k] = v.pos[k];
     }
-    float t_min = ((g.box_min[0] - r.ro[0]) / (r.rd[0]));
-    float t_max = ((g.box_max[0] - r.ro[0]) / (r.rd[0]));
+    float t_min = (g.box_min[0] - r.ro[0]) / r.rd[0];
+    float t_max = (g.box_max[0] - r.ro[0]) / r.rd[0];
     if (t_min > t_max) { float t = t_min; t_min = t_max; t_max = t; }
-    float t_y_min = ((g.box_min[1] - r.ro[1]) / (r.rd[1]));
-    float t_y_max = ((g.box_max[1] - r.ro[1]) / (r.rd[1]));
+    float t_y_min = (g.box_min[1] - r.ro[1]) / r.rd[1];
+    float t_y_max = (g.box_max[1] - r.ro[1]) / r.rd[1];
     if (t_y_min > t_y_max) { float t = t_y_min; t_y_min = t_y_max; t_y_max = t; }
     bool hit = !((t_min > t_y_max) || (t_y_min > t_max));
     if (t_y_min > t_min) t_min = t_y_min;
     if (t_y_max < t_max) t_max = t_y_max;
-    float t_z_min = ((g.box_min[2] - r.ro[2]) / (r.rd[2]));
-    float t_z_max = ((g.box_max[2] - r.ro[2]) / (r.rd[2]));
+    float t_z_min = (g.box_min[2] - r.ro[2]) / r.rd[2];
+    float t_z_max = (g.box_max[2] - r.ro[2]) / r.rd[2];
     if (t_z_min > t_z_max) { float t = t_z_min; t_z_min = t_z_max; t_z_max = t; }
     hit = hit && !((t_min > t_z_max) || (t_z_min > t_max));
     if (t_z_min > t_min) t_min = t_z_min;
@@ -82,9 +84,101 @@ __device__ __forceinline__ uint32_t unorm8(float v)
 
 __device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
+struct Accum {
+    float cr, cg, cb, alpha; // colour in 0..255 texel units while marching when the TF is off
+};
+
+// Trilinear filter of the 8 corner texels (c[z][y][x] as RGBA8 words) + transfer function (wgsl:145-147)
+// + Beer-Lambert opacity (wgsl:150) + front-to-back blend (wgsl:158-159).  Returns alpha >= 1 (wgsl:176).
+template <bool ALPHA_ONLY, bool USE_TF>
+__device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
+                                      Accum &acc)
+{
+    auto tri = [&](int k) -> float {
+        const float a00 = ub(c[0], k), a10 = ub(c[2], k), a01 = ub(c[4], k), a11 = ub(c[6], k);
+        const float c00 = __builtin_fmaf(wx, ub(c[1], k) - a00, a00);
+        const float c10 = __builtin_fmaf(wx, ub(c[3], k) - a10, a10);
+        const float c01 = __builtin_fmaf(wx, ub(c[5], k) - a01, a01);
+        const float c11 = __builtin_fmaf(wx, ub(c[7], k) - a11, a11);
+        const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
+        const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
+        return __builtin_fmaf(wz, c1 - c0, c0);
+    };
+    const float a255 = tri(3);
+    // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a255 * kexp), a255 = filtered alpha in 0..255
+    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
+    const float om = 1.0f - acc.alpha;
+    const float w = om * alpha_src;
+    if (USE_TF) {
+        // piecewise-linear in a with the breakpoint at 0.5: A->B below, B->C above
+        const float a = a255 * (1.0f / 255.0f);
+        const bool hi = a >= 0.5f;
+        const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
+        const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
+        const float s1 = hi ? P.col_b[1] : P.col_a[1], e1 = hi ? P.col_c[1] : P.col_b[1];
+        const float s2 = hi ? P.col_b[2] : P.col_a[2], e2 = hi ? P.col_c[2] : P.col_b[2];
+        acc.cr = __builtin_fmaf(w, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
+        acc.cg = __builtin_fmaf(w, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
+        acc.cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
+    } else if (ALPHA_ONLY) {
+        acc.cr = __builtin_fmaf(w, a255, acc.cr); // r == g == b == a for scalar volumes
+    } else {
+        acc.cr = __builtin_fmaf(w, tri(0), acc.cr);
+        acc.cg = __builtin_fmaf(w, tri(1), acc.cg);
+        acc.cb = __builtin_fmaf(w, tri(2), acc.cb);
+    }
+    acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
+    return acc.alpha >= 1.0f;
+}
+
+template <bool ALPHA_ONLY, bool USE_TF>
+__device__ __forceinline__ void finish_colour(Accum &acc)
+{
+    if (!USE_TF) {
+        const float s = 1.0f / 255.0f;
+        acc.cr *= s;
+        if (ALPHA_ONLY) { acc.cg = acc.cr; acc.cb = acc.cr; }
+        else { acc.cg *= s; acc.cb *= s; }
+    }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void store_pixel(const VrmViewDesc &v, const VrmMarchParams &P, uint32_t px, uint32_t py,
+                                            const Accum &acc, const Ray &ray, uint32_t iters, uint32_t n_inside)
+{
+    const uint32_t packed = unorm8(acc.cr) | (unorm8(acc.cg) << 8) | (unorm8(acc.cb) << 16) | (unorm8(acc.alpha) << 24);
+    v.out[(size_t)py * P.pitch_px + px] = packed;
+    if (DIAG) {
+        const size_t o = (size_t)py * P.width + px;
+        if (v.diag_rgba) reinterpret_cast<float4 *>(v.diag_rgba)[o] = make_float4(acc.cr, acc.cg, acc.cb, acc.alpha);
+        if (v.diag_iters) v.diag_iters[o] = iters;
+        if (v.diag_geom) {
+            float4 *gq = reinterpret_cast<float4 *>(v.diag_geom) + 2 * o;
+            gq[0] = make_float4(ray.rd[0], ray.rd[1], ray.rd[2], ray.hit ? ray.t_min : 0.0f);
+            gq[1] = make_float4(ray.hit ? ray.t_max : 0.0f, (float)n_inside, ray.hit ? 1.0f : 0.0f, (float)iters);
+        }
+    }
+}
+
+// 8 corner texels straight from the x-fastest global volume, clamp-to-edge (texture_3d.rs:66-76)
+__device__ __forceinline__ void fetch_global(const VrmGridDev &g, int ix, int iy, int iz, uint32_t c[8])
+{
+    const uint32_t X = g.dim[0], Y = g.dim[1];
+    const int mx = (int)g.dim[0] - 1, my = (int)g.dim[1] - 1, mz = (int)g.dim[2] - 1;
+    const uint32_t x0 = (uint32_t)min(max(ix, 0), mx), x1 = (uint32_t)max(min(ix + 1, mx), 0);
+    const uint32_t y0 = (uint32_t)min(max(iy, 0), my), y1 = (uint32_t)max(min(iy + 1, my), 0);
+    const uint32_t z0 = (uint32_t)min(max(iz, 0), mz), z1 = (uint32_t)max(min(iz + 1, mz), 0);
+    const size_t r00 = ((size_t)z0 * Y + y0) * X, r10 = ((size_t)z0 * Y + y1) * X;
+    const size_t r01 = ((size_t)z1 * Y + y0) * X, r11 = ((size_t)z1 * Y + y1) * X;
+    c[0] = g.vox[r00 + x0]; c[1] = g.vox[r00 + x1];
+    c[2] = g.vox[r10 + x0]; c[3] = g.vox[r10 + x1];
+    c[4] = g.vox[r01 + x0]; c[5] = g.vox[r01 + x1];
+    c[6] = g.vox[r11 + x0]; c[7] = g.vox[r11 + x1];
+}
+
 // ---------------------------------------------------------------------------------------------
-// Variant 0: linear x-fastest RGBA8 volume, software trilinear straight from global memory.
-// One thread per pixel, one wave per 8x8 pixel tile.  Correctness baseline.
+// Variant 0: software trilinear straight from global memory.  One thread per pixel, one wave per
+// 8x8 pixel tile, 4 waves per workgroup.  Correctness baseline and A/B reference for variant 1.
 // ---------------------------------------------------------------------------------------------
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG>
 __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams P)
@@ -98,17 +192,12 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
     const uint32_t py = ty * TILE + (wave >> 1) * 8u + (lane >> 3);
     if (px >= P.width || py >= P.height) return;
     const VrmViewDesc &v = P.views[view];
-
     const Ray ray = setup_ray(v, g, px, py, P.width, P.height);
 
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, alpha = 0.0f; // colour accumulators in 0..255 texel units when !USE_TF
+    Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t iters = 0, n_inside = 0;
-
     if (ray.hit) {
-        // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a255 * kexp), a255 = filtered alpha in 0..255
         const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
-        const uint32_t X = g.dim[0], Y = g.dim[1];
-        const int mx = (int)g.dim[0] - 1, my = (int)g.dim[1] - 1, mz = (int)g.dim[2] - 1;
         float dt = ray.t_min;
         for (int i = 0; i < VRM_MAX_STEP_AMOUNT; ++i) {
             ++iters;
@@ -124,78 +213,191 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
                 const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
                 const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
                 const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
-                const float wx = u0 - f0, wy = u1 - f1, wz = u2 - f2;
-                const int ix = (int)f0, iy = (int)f1, iz = (int)f2;
-                const uint32_t x0 = (uint32_t)max(ix, 0), x1 = (uint32_t)min(ix + 1, mx);
-                const uint32_t y0 = (uint32_t)max(iy, 0), y1 = (uint32_t)min(iy + 1, my);
-                const uint32_t z0 = (uint32_t)max(iz, 0), z1 = (uint32_t)min(iz + 1, mz);
-                const size_t r00 = ((size_t)z0 * Y + y0) * X, r10 = ((size_t)z0 * Y + y1) * X;
-                const size_t r01 = ((size_t)z1 * Y + y0) * X, r11 = ((size_t)z1 * Y + y1) * X;
-                const uint32_t v000 = g.vox[r00 + x0], v100 = g.vox[r00 + x1];
-                const uint32_t v010 = g.vox[r10 + x0], v110 = g.vox[r10 + x1];
-                const uint32_t v001 = g.vox[r01 + x0], v101 = g.vox[r01 + x1];
-                const uint32_t v011 = g.vox[r11 + x0], v111 = g.vox[r11 + x1];
-
-                auto tri = [&](int k) -> float {
-                    const float a00 = ub(v000, k), a10 = ub(v010, k), a01 = ub(v001, k), a11 = ub(v011, k);
-                    const float c00 = __builtin_fmaf(wx, ub(v100, k) - a00, a00);
-                    const float c10 = __builtin_fmaf(wx, ub(v110, k) - a10, a10);
-                    const float c01 = __builtin_fmaf(wx, ub(v101, k) - a01, a01);
-                    const float c11 = __builtin_fmaf(wx, ub(v111, k) - a11, a11);
-                    const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
-                    const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
-                    return __builtin_fmaf(wz, c1 - c0, c0);
-                };
-                const float a255 = tri(3);
-                const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
-                const float om = 1.0f - alpha;
-                const float w = om * alpha_src;
-                if (USE_TF) {
-                    // wgsl:145-147: piecewise-linear in a with the breakpoint at 0.5
-                    const float a = a255 * (1.0f / 255.0f);
-                    const bool hi = a >= 0.5f;
-                    const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
-                    const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
-                    const float s1 = hi ? P.col_b[1] : P.col_a[1], e1 = hi ? P.col_c[1] : P.col_b[1];
-                    const float s2 = hi ? P.col_b[2] : P.col_a[2], e2 = hi ? P.col_c[2] : P.col_b[2];
-                    cr = __builtin_fmaf(w, __builtin_fmaf(t, e0 - s0, s0), cr);
-                    cg = __builtin_fmaf(w, __builtin_fmaf(t, e1 - s1, s1), cg);
-                    cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), cb);
-                } else if (ALPHA_ONLY) {
-                    cr = __builtin_fmaf(w, a255, cr); // r == g == b == a for scalar volumes
-                } else {
-                    cr = __builtin_fmaf(w, tri(0), cr);
-                    cg = __builtin_fmaf(w, tri(1), cg);
-                    cb = __builtin_fmaf(w, tri(2), cb);
-                }
-                alpha = __builtin_fmaf(om, alpha_src, alpha);
-                if (alpha >= 1.0f) break; // wgsl:176-178
+                uint32_t c[8];
+                fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+                if (shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc)) break; // wgsl:176-178
             }
             dt += VRM_STEP_SIZE;          // wgsl:181, running f32 sum
             if (dt >= ray.t_max) break;   // wgsl:184-186
         }
-        if (!USE_TF) {
-            const float s = 1.0f / 255.0f;
-            if (ALPHA_ONLY) { cr *= s; cg = cr; cb = cr; }
-            else { cr *= s; cg *= s; cb *= s; }
-        }
+        finish_colour<ALPHA_ONLY, USE_TF>(acc);
+    }
+    store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant 1: per-wave LDS staging.
+//
+// One wave (= one 64-thread workgroup) owns an 8x8 pixel tile and marches its 64 rays in lockstep,
+// K steps at a time.  For each chunk of K steps the wave computes the axis-aligned box (in texel
+// space) that holds every texel any of its rays can touch during the chunk, copies that box --
+// clamp-to-edge already applied -- from the x-fastest global volume into LDS with row-coalesced
+// loads (lanes run along x), and then takes all 8*K gathers per ray from LDS: one global line is
+// touched once per chunk instead of once per corner per sample.  A box that does not fit the LDS
+// budget (far-away cameras: one pixel spans many voxels) falls back to global gathers for that
+// chunk.  The dt lattice, the sample positions and the in-box test are the same exact sequence as
+// in variant 0 / the oracle; only where the texels are read from differs.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, int PX, int CAP, int K>
+__global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
+{
+    static_assert(PX >= 4 && PX <= 64, "row pitch");
+    __shared__ uint32_t tile[CAP];
+    const VrmGridDev &g = P.grid;
+    const uint32_t view = blockIdx.y;
+    // Tile order.  The image is cut into 64x64-pixel super-blocks (8x8 wave tiles).  Workgroup b runs on the
+    // XCD group b % 8 (hardware round-robin); that group owns the super-blocks on the diagonals
+    // (sbx + sby) % 8 == b % 8 and walks through them one after the other.  So the ~320 waves an XCD has in
+    // flight cover a few compact image patches (=> a compact part of the volume in its L2), while every XCD
+    // gets the same mix of centre (long rays) and border (misses) super-blocks: the in-order dispatcher
+    // stalls on the slowest XCD, so balance matters more than anything else here.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t j = slot >> 6, within = slot & 63u;
+    const uint32_t per_row = P.sblocks_x >> 3;             // sblocks_x is padded to a multiple of 8
+    const uint32_t sby = j / per_row, m = j - sby * per_row;
+    const uint32_t sbx = ((xcd - sby) & 7u) + 8u * m;
+    const uint32_t tx = sbx * 8u + (within & 7u), ty = sby * 8u + (within >> 3);
+    if (tx * 8u >= P.width || ty * 8u >= P.height) return; // wave-uniform
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    const bool in_image = px < P.width && py < P.height;
+    const VrmViewDesc &v = P.views[view];
+    const Ray ray = setup_ray(v, g, in_image ? px : 0u, in_image ? py : 0u, P.width, P.height);
+
+    Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t iters = 0, n_inside = 0;
+    const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
+    bool active = in_image && ray.hit;
+    float dt = ray.t_min;
+
+    // staging lane map: PX lanes along x per row, RPI rows per pass
+    constexpr int RPI = 64 / PX;
+    const int ex = (int)lane % PX, er = (int)lane / PX;
+
+    // per-step advance of a ray in texel space, bounded over the wave once: every chunk's box is then
+    // [min start, max start] widened by k steps of it, for any k, without another reduction.  The 1 % slack
+    // covers the drift of the running f32 dt sum (an ulp of dt per step, 0.4 % of a step at dt = 100).
+    float dlo[3], dhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float du = ray.rd[a] * g.tex_scale[a] * (VRM_STEP_SIZE * 1.01f);
+        dlo[a] = fminf(wave_min(active ? du : __builtin_inff()), 0.0f);
+        dhi[a] = fmaxf(wave_max(active ? du : -__builtin_inff()), 0.0f);
     }
 
-    const uint32_t packed = unorm8(cr) | (unorm8(cg) << 8) | (unorm8(cb) << 16) | (unorm8(alpha) << 24);
-    v.out[(size_t)py * P.pitch_px + px] = packed;
-    if (DIAG) {
-        const size_t o = (size_t)py * P.width + px;
-        if (v.diag_rgba) {
-            float4 c = make_float4(cr, cg, cb, alpha);
-            reinterpret_cast<float4 *>(v.diag_rgba)[o] = c;
+    int i = 0;
+    while (i < VRM_MAX_STEP_AMOUNT) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+
+        // ---- texel-space bounding box of this chunk, over the active rays ------------------------
+        float slo[3], shi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float ua = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+            slo[a] = wave_min(active ? ua : __builtin_inff());
+            shi[a] = wave_max(active ? ua : -__builtin_inff());
         }
-        if (v.diag_iters) v.diag_iters[o] = iters;
-        if (v.diag_geom) {
-            float4 *gq = reinterpret_cast<float4 *>(v.diag_geom) + 2 * o;
-            gq[0] = make_float4(ray.rd[0], ray.rd[1], ray.rd[2], ray.hit ? ray.t_min : 0.0f);
-            gq[1] = make_float4(ray.hit ? ray.t_max : 0.0f, (float)n_inside, ray.hit ? 1.0f : 0.0f, (float)iters);
+        // largest chunk length (K, K/2, ..., 1) whose box fits the LDS tile
+        int kk = min(K, VRM_MAX_STEP_AMOUNT - i);
+        int ilo[3], ihi[3], nx, ny, nz;
+        bool none, fits;
+        for (;;) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test
+                const float lo = fmaxf(slo[a] + (float)kk * dlo[a] - 0.01f, -1.0f);
+                const float hi = fminf(shi[a] + (float)kk * dhi[a] + 0.01f, (float)g.dim[a] - 0.5f);
+                ilo[a] = uni((int)floorf(lo));
+                ihi[a] = uni((int)floorf(hi) + 1);
+            }
+            nx = ihi[0] - ilo[0] + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
+            none = nx < 2 || ny < 2 || nz < 2;                         // whole chunk lies outside the box
+            fits = !none && nx <= PX && (long long)ny * nz * PX <= (long long)CAP;
+            if (fits || none || kk == 1) break;
+            kk >>= 1;
         }
+        if (!fits && !none) kk = min(8, VRM_MAX_STEP_AMOUNT - i);      // global-gather fallback chunk
+
+        if (fits) {
+            // ---- stage the box: rows along x, clamp-to-edge applied here --------------------------
+            const int rows = ny * nz;
+            const float inv_ny = 1.0f / (float)ny;
+            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
+            const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
+            const bool lane_on = er < RPI && ex < nx;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
+#pragma unroll 4
+            for (int row = er; row < rows; row += RPI) {
+                // row -> (ey, ez): (row + 0.5)/ny is at least 0.5/ny away from an integer, far above f32 error
+                const int ez = (int)(((float)row + 0.5f) * inv_ny);
+                const int ey = row - ez * ny;
+                const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
+                const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
+                if (lane_on) tile[row * PX + ex] = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // writes before the gathers below
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- K lockstep steps -------------------------------------------------------------------------
+        const int slice = ny * PX;
+        for (int j = 0; j < kk; ++j) {
+            if (active) {
+                if (DIAG) ++iters;
+                const float p0 = ray.ro[0] + ray.rd[0] * dt;
+                const float p1 = ray.ro[1] + ray.rd[1] * dt;
+                const float p2 = ray.ro[2] + ray.rd[2] * dt;
+                const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
+                                    (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
+                bool done = false;
+                if (inside) {
+                    if (DIAG) ++n_inside;
+                    const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
+                    const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
+                    const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
+                    const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
+                    uint32_t c[8];
+                    if (fits) {
+                        // the box holds floor(u) and floor(u)+1 of every in-box sample of the chunk by construction;
+                        // the clamps only keep a rounding surprise from reading another wave's... nothing: LDS is per wave
+                        const int lx = min(max((int)f0 - ilo[0], 0), nx - 2);
+                        const int ly = min(max((int)f1 - ilo[1], 0), ny - 2);
+                        const int lz = min(max((int)f2 - ilo[2], 0), nz - 2);
+                        const int a0 = (lz * ny + ly) * PX + lx;
+                        c[0] = tile[a0];             c[1] = tile[a0 + 1];
+                        c[2] = tile[a0 + PX];        c[3] = tile[a0 + PX + 1];
+                        c[4] = tile[a0 + slice];     c[5] = tile[a0 + slice + 1];
+                        c[6] = tile[a0 + slice + PX]; c[7] = tile[a0 + slice + PX + 1];
+                    } else {
+                        fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+                    }
+                    done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                }
+                if (!done) {
+                    dt += VRM_STEP_SIZE;
+                    done = dt >= ray.t_max;
+                }
+                active = !done;
+            }
+        }
+        i += kk;
     }
+    finish_colour<ALPHA_ONLY, USE_TF>(acc);
+    if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -274,7 +476,7 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const uint8_t *__r
             val = (float)raw[i];
             denom = 255.0f;
         }
-        float q = ((val) / (denom)) * 255.0f;
+        float q = (val / denom) * 255.0f;
         q = fminf(fmaxf(q, 0.0f), 255.0f);
         dst[i] = (uint32_t)q * 0x01010101u;
     }
@@ -306,25 +508,33 @@ inline uint32_t stream_blocks(size_t n)
     return (uint32_t)(b < cap ? (b ? b : 1) : cap);
 }
 
+template <bool A, bool T, bool D>
+void launch_variant(const VrmMarchParams &p, uint32_t n_views, int variant, hipStream_t stream)
+{
+    if (variant == 0) {
+        const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
+        hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
+    } else {
+        const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
+        hipLaunchKernelGGL((march_lds_kernel<A, T, D, 20, 4096, 16>), grid, block, 0, stream, p);
+    }
+}
+
 } // namespace
 
 hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, hipStream_t stream)
 {
-    (void)variant;
-    const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
     const bool tf = p.use_tf != 0;
     const bool alpha_only = p.grid.scalar != 0;
-#define VRM_LAUNCH(A, T, D) hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p)
     if (diagnostics) {
-        if (tf) VRM_LAUNCH(true, true, true);
-        else if (alpha_only) VRM_LAUNCH(true, false, true);
-        else VRM_LAUNCH(false, false, true);
+        if (tf) launch_variant<true, true, true>(p, n_views, variant, stream);
+        else if (alpha_only) launch_variant<true, false, true>(p, n_views, variant, stream);
+        else launch_variant<false, false, true>(p, n_views, variant, stream);
     } else {
-        if (tf) VRM_LAUNCH(true, true, false);
-        else if (alpha_only) VRM_LAUNCH(true, false, false);
-        else VRM_LAUNCH(false, false, false);
+        if (tf) launch_variant<true, true, false>(p, n_views, variant, stream);
+        else if (alpha_only) launch_variant<true, false, false>(p, n_views, variant, stream);
+        else launch_variant<false, false, false>(p, n_views, variant, stream);
     }
-#undef VRM_LAUNCH
     return hipGetLastError();
 }
 
