@@ -33,17 +33,19 @@ def vr():
     return volume_renderer_amd
 
 
-KERNEL_VARIANTS = [0, 1]  # 0: global gathers (baseline), 1: per-wave LDS staging (default)
+# (kernel variant, exact empty-space skipping): 0 = global gathers (baseline), 1 = per-wave LDS staging (default)
+KERNEL_VARIANTS = [(0, 0), (1, 0), (1, 1)]
 
 
-@pytest.fixture(params=KERNEL_VARIANTS, ids=[f"k{k}" for k in KERNEL_VARIANTS])
+@pytest.fixture(params=KERNEL_VARIANTS, ids=[f"k{k}{'s' if s else ''}" for k, s in KERNEL_VARIANTS])
 def rm(vr, request):
-    """A fresh RayMarcher on GPU 0, once per kernel variant.  GPU tests fail loudly if the HIP library or the
-    device is missing."""
+    """A fresh RayMarcher on GPU 0, once per kernel configuration.  GPU tests fail loudly if the HIP library or
+    the device is missing."""
     if not have_gpu():
         pytest.skip("no /dev/kfd: GPU tests only run on the GPU box (-m gpu)")
     r = vr.RayMarcher(0, 256, 256)
-    r.set_option(vr.OPT_KERNEL, request.param)
+    r.set_option(vr.OPT_KERNEL, request.param[0])
+    r.set_option(vr.OPT_SKIP_EMPTY, request.param[1])
     yield r
     r.close()
 

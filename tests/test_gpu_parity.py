@@ -172,6 +172,36 @@ def test_scalar_and_rgba_filters_agree(rm, vr, orc):
     assert np.abs(a["f32"] - b["f32"]).max() < 1e-5
 
 
+def test_empty_space_skipping_is_bit_exact(vr, orc):
+    """skipped samples contribute exactly 0 (a = 0 => alpha_src = 1 - exp(0) = 0), and the dt lattice is advanced
+    with the same running f32 sum: image, f32 accumulators and iteration counts must be IDENTICAL with the option
+    on and off, and the kernel variants must agree with each other as well."""
+    if not __import__("os").path.exists("/dev/kfd"):
+        pytest.skip("no GPU")
+    rm = vr.RayMarcher(0, 256, 256)
+    dens = synth.blobs_density((96, 80, 112))
+    rgba = synth.quantize_rgba8(synth.blobs_rgba_f32((96, 80, 112)))
+    island = np.zeros((64, 64, 64, 4), np.uint8)           # one small occupied island in a big empty box
+    island[20:29, 40:44, 8:19] = (255, 10, 90, 200)
+    assert (dens == 0).mean() > 0.5
+    for vox, att, tf in [(rgba, 1.0, False), (rgba, 40.0, True), (island, 25.0, False)]:
+        configure(rm, vox, att, tf)
+        for ix, iy in [(1, 3), (4, 6), (7, 1)]:
+            cam = sphere_cam(orc, ix, iy)
+            res = {}
+            for k, s in [(0, 0), (1, 0), (1, 1)]:
+                rm.set_option(vr.OPT_KERNEL, k)
+                rm.set_option(vr.OPT_SKIP_EMPTY, s)
+                res[(k, s)] = draw(rm, vr, cam, 160, 120)
+            base = res[(1, 0)]
+            for key in [(0, 0), (1, 1)]:
+                assert np.array_equal(res[key]["rgba8"], base["rgba8"]), key
+                assert np.array_equal(res[key]["f32"].view(np.uint32), base["f32"].view(np.uint32)), key
+                assert np.array_equal(res[key]["iters"], base["iters"]), key
+                assert np.array_equal(res[key]["geo"].view(np.uint32), base["geo"].view(np.uint32)), key
+    rm.close()
+
+
 def test_batch_equals_single_draws(rm, vr, orc):
     vox = synth.quantize_rgba8(synth.blobs_rgba_f32((32, 24, 40)))
     configure(rm, vox, 2.0, False)

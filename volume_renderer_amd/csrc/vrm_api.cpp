@@ -69,6 +69,9 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     if (ctx->vox) HIP_TRY(hipFree(ctx->vox));
     ctx->vox = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
+    if (ctx->occ) HIP_TRY(hipFree(ctx->occ));
+    ctx->occ = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 7) / 8) * ((y + 7) / 8) * ((z + 7) / 8)));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
     return VRM_OK;
@@ -82,6 +85,7 @@ extern "C" int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     if (rc) return rc;
     // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
     HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
+    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
     ctx->scalar = false;
     ctx->attenuation = 1.0f;   // grid.rs:100,197
     tf_defaults(&ctx->tf);     // grid.rs:198
@@ -138,6 +142,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
         (void)hipEventDestroy(p.second);
     }
     if (ctx->vox) (void)hipFree(ctx->vox);
+    if (ctx->occ) (void)hipFree(ctx->occ);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     if (ctx->views_dev) (void)hipFree(ctx->views_dev);
     if (ctx->views_host) (void)hipHostFree(ctx->views_host);
@@ -149,6 +154,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
 // after new voxel data: is the volume scalar (r == g == b == a)?  (selects the 1-channel filter)
 static int grid_finish_upload(vrm_ctx *ctx)
 {
+    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->flag_dev, 0, 4, ctx->stream));
     HIP_TRY(vrm_launch_detect_nonscalar(ctx->vox, ctx->vox_words, ctx->flag_dev, ctx->stream));
     uint32_t flag = 1;
@@ -429,8 +435,10 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     VrmGridDev &g = p->grid;
     g.vox = ctx->vox;
     g.scalar = ctx->scalar ? 1u : 0u;
+    g.occ = ctx->occ;
     for (int i = 0; i < 3; ++i) {
         g.dim[i] = ctx->dim[i];
+        g.occ_dim[i] = (ctx->dim[i] + 7) / 8;
         g.box_min[i] = u.box_min[i];
         g.box_size[i] = u.box_size[i];
         g.box_max[i] = u.box_min[i] + u.box_size[i]; // wgsl:202,250
@@ -513,7 +521,7 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
         ctx->prof_used++;
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, diag, ctx->stream));
+    HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, diag, ctx->opt_skip != 0, ctx->stream));
     if (e1) HIP_TRY(hipEventRecord(e1, ctx->stream));
     for (uint32_t i = 0; i < n; ++i) {
         vrm_image *img = targets[i];

@@ -22,6 +22,8 @@ struct VrmGridDev {
     const uint32_t *vox; // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211)
     uint32_t dim[3];
     uint32_t scalar;     // 1 => every voxel has r == g == b == a (DAT volumes, dat.rs:74)
+    const uint8_t *occ;  // max alpha per 8x8x8-voxel cell, x fastest (exact empty-space skipping)
+    uint32_t occ_dim[3]; // ceil(dim / 8)
     float box_min[3];    // VoxelGridUniform.box_min (grid.rs:271)
     float box_max[3];    // box_min + box_size, rounded as the shader computes it (wgsl:202,250)
     float box_size[3];
@@ -41,7 +43,9 @@ struct VrmMarchParams {
 };
 
 // launchers implemented in vrm_kernels.hip
-hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, hipStream_t stream);
+hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, bool skip_empty,
+                            hipStream_t stream);
+hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream);
 hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream);
 hipError_t vrm_launch_quantize_f32(const float *src_czyx, uint32_t channels, size_t n_voxels, uint32_t *dst, hipStream_t stream);
 hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sample, size_t n_voxels, uint32_t *dst,

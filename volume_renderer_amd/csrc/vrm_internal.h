@@ -17,6 +17,7 @@ struct vrm_ctx {
     uint32_t *vox = nullptr; // RGBA8 words, x fastest
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere
+    uint8_t *occ = nullptr;  // max alpha per 8^3 cell, rebuilt whenever the voxels change
     float attenuation = 1.0f;
     vrm_transfer_function tf;
     uint32_t *flag_dev = nullptr; // 1 word scratch for detect_nonscalar

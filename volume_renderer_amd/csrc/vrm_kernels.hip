@@ -252,7 +252,7 @@ __device__ __forceinline__ float wave_max(float v)
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, int PX, int CAP, int K>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int PX, int CAP, int K>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
     static_assert(PX >= 4 && PX <= 64, "row pitch");
@@ -332,13 +332,32 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         }
         if (!fits && !none) kk = min(8, VRM_MAX_STEP_AMOUNT - i);      // global-gather fallback chunk
 
-        if (fits) {
+        // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
+        // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
+        // the dt lattice has to advance.  First a look-up in the 8^3-cell max-alpha grid, later the staged texels.
+        bool empty = none;
+        if (SKIP && !none && (fits || kk <= 8)) {
+            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
+            const int c0x = max(ilo[0], 0) >> 3, c0y = max(ilo[1], 0) >> 3, c0z = max(ilo[2], 0) >> 3;
+            const int ncx = (min(ihi[0], mxx) >> 3) - c0x + 1, ncy = (min(ihi[1], mxy) >> 3) - c0y + 1,
+                      ncz = (min(ihi[2], mxz) >> 3) - c0z + 1;
+            if (ncx <= 4 && ncy <= 4 && ncz <= 4) {
+                const int cx = (int)lane & 3, cy = ((int)lane >> 2) & 3, cz = (int)lane >> 4;
+                bool occ = false;
+                if (cx < ncx && cy < ncy && cz < ncz)
+                    occ = g.occ[((size_t)(c0z + cz) * g.occ_dim[1] + (size_t)(c0y + cy)) * g.occ_dim[0] + (size_t)(c0x + cx)] != 0;
+                empty = __builtin_amdgcn_ballot_w64(occ) == 0ull;
+            }
+        }
+
+        if (fits && !empty) {
             // ---- stage the box: rows along x, clamp-to-edge applied here --------------------------
             const int rows = ny * nz;
             const float inv_ny = 1.0f / (float)ny;
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
             const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
             const bool lane_on = er < RPI && ex < nx;
+            uint32_t seen = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
 #pragma unroll 4
             for (int row = er; row < rows; row += RPI) {
@@ -347,10 +366,33 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 const int ey = row - ez * ny;
                 const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                 const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
-                if (lane_on) tile[row * PX + ex] = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
+                if (lane_on) {
+                    const uint32_t w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
+                    tile[row * PX + ex] = w;
+                    seen |= w;
+                }
             }
+            if (SKIP) empty = __builtin_amdgcn_ballot_w64((seen >> 24) != 0u) == 0ull; // staged box is the exact touch set
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // writes before the gathers below
             __builtin_amdgcn_wave_barrier();
+        }
+
+        if (empty) {
+            // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
+            for (int j = 0; j < kk; ++j) {
+                if (active) {
+                    if (DIAG) {
+                        ++iters;
+                        const float p0 = ray.ro[0] + ray.rd[0] * dt, p1 = ray.ro[1] + ray.rd[1] * dt, p2 = ray.ro[2] + ray.rd[2] * dt;
+                        n_inside += ((p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
+                                     (p1 < g.box_max[1]) & (p2 < g.box_max[2])) ? 1u : 0u;
+                    }
+                    dt += VRM_STEP_SIZE;
+                    active = !(dt >= ray.t_max);
+                }
+            }
+            i += kk;
+            continue;
         }
 
         // ---- K lockstep steps -------------------------------------------------------------------------
@@ -482,6 +524,25 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const uint8_t *__r
     }
 }
 
+// max alpha of every 8x8x8-voxel cell (one wave per cell): the look-up behind exact empty-space skipping
+__global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
+                                                             uint32_t cx_n, uint32_t cy_n, uint8_t *__restrict__ occ)
+{
+    const uint32_t cell = blockIdx.x;
+    const uint32_t cz = cell / (cx_n * cy_n), r = cell - cz * cx_n * cy_n, cy = r / cx_n, cx = r - cy * cx_n;
+    const uint32_t lx = threadIdx.x & 7u, ly = threadIdx.x >> 3;
+    const uint32_t x = cx * 8u + lx, y = cy * 8u + ly;
+    uint32_t m = 0;
+    if (x < X && y < Y)
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t z = cz * 8u + k;
+            if (z < Z) m = max(m, vox[((size_t)z * Y + y) * X + x] >> 24);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (threadIdx.x == 0) occ[cell] = (uint8_t)m;
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(uint32_t *dst, size_t n, uint32_t value)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -509,31 +570,39 @@ inline uint32_t stream_blocks(size_t n)
 }
 
 template <bool A, bool T, bool D>
-void launch_variant(const VrmMarchParams &p, uint32_t n_views, int variant, hipStream_t stream)
+void launch_variant(const VrmMarchParams &p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
 {
     if (variant == 0) {
         const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
     } else {
         const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
-        hipLaunchKernelGGL((march_lds_kernel<A, T, D, 20, 4096, 16>), grid, block, 0, stream, p);
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, 20, 4096, 16>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, 20, 4096, 16>), grid, block, 0, stream, p);
     }
 }
 
 } // namespace
 
-hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, hipStream_t stream)
+hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
+{
+    const uint32_t cx = (dim[0] + 7) / 8, cy = (dim[1] + 7) / 8, cz = (dim[2] + 7) / 8;
+    hipLaunchKernelGGL(build_occupancy_kernel, dim3(cx * cy * cz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], cx, cy, occ);
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, bool skip, hipStream_t stream)
 {
     const bool tf = p.use_tf != 0;
     const bool alpha_only = p.grid.scalar != 0;
     if (diagnostics) {
-        if (tf) launch_variant<true, true, true>(p, n_views, variant, stream);
-        else if (alpha_only) launch_variant<true, false, true>(p, n_views, variant, stream);
-        else launch_variant<false, false, true>(p, n_views, variant, stream);
+        if (tf) launch_variant<true, true, true>(p, n_views, variant, skip, stream);
+        else if (alpha_only) launch_variant<true, false, true>(p, n_views, variant, skip, stream);
+        else launch_variant<false, false, true>(p, n_views, variant, skip, stream);
     } else {
-        if (tf) launch_variant<true, true, false>(p, n_views, variant, stream);
-        else if (alpha_only) launch_variant<true, false, false>(p, n_views, variant, stream);
-        else launch_variant<false, false, false>(p, n_views, variant, stream);
+        if (tf) launch_variant<true, true, false>(p, n_views, variant, skip, stream);
+        else if (alpha_only) launch_variant<true, false, false>(p, n_views, variant, skip, stream);
+        else launch_variant<false, false, false>(p, n_views, variant, skip, stream);
     }
     return hipGetLastError();
 }
