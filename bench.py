@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--tf", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32, help="views per launch")
     ap.add_argument("--kernel", type=int, default=1, help="march kernel variant (0: global gathers, 1: LDS-staged)")
-    ap.add_argument("--skip-empty", type=int, default=0)
+    ap.add_argument("--skip-empty", type=int, default=1, help="exact empty-space skipping (bit-identical image); "
+                    "the no-skip rate is measured too and reported as views_per_s_no_skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the export rendered by the CPU baseline (at most)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU baseline after this much CPU-side wall time")
@@ -136,6 +137,22 @@ def main():
     rm.set_option(vr.OPT_PROFILE, 0)
     n_ref = vd.sum_over_ranks(n_ref_mine, dev)
 
+    # the same export with skipping off (every reference sample actually taken), one step, for transparency
+    no_skip = None
+    if a.skip_empty:
+        rm.set_option(vr.OPT_SKIP_EMPTY, 0)
+        step()
+        rm.synchronize()
+        vd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        rm.synchronize()
+        torch.cuda.synchronize()
+        vd.barrier()
+        no_skip = n_views / vd.max_over_ranks(time.perf_counter() - t0, dev)
+        rm.set_option(vr.OPT_SKIP_EMPTY, 1)
+
     views_per_s = n_views * a.steps / elapsed
     gsamples = n_ref * a.steps / elapsed / 1e9
 
@@ -162,6 +179,7 @@ def main():
         "gsamples_per_s": round(gsamples, 3), "reference_samples_per_step": int(n_ref),
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
         "volume_broadcast_ms": round(bcast_ms, 2), "roofline": roofline,
+        "views_per_s_no_skip": None if no_skip is None else round(no_skip, 3),
     }
 
     # ---- CPU baseline: the oracle ("port"; the wgpu reference cannot run here) on a bounded sample -------

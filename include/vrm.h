@@ -165,13 +165,15 @@ VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, floa
 /* loaders/dat.rs:10-82: parse `ObjectFileName/Resolution/Format`, read the RAW next to it, upload. */
 VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
 
-/* ---- build extensions (no reference counterpart; off unless asked for) ---------------------- */
+/* ---- build extensions (no reference counterpart) --------------------------------------------- */
 
 typedef enum vrm_option {
-    VRM_OPT_KERNEL = 0,       /* kernel variant; 0 = default */
-    VRM_OPT_SKIP_EMPTY = 1,   /* exact empty-space skipping (skipped samples contribute exactly 0) */
-    VRM_OPT_PROFILE = 2,      /* record hipEvents around every march launch */
-    VRM_OPT_DIAGNOSTICS = 3   /* also write per-pixel f32 colour and iteration counts */
+    VRM_OPT_KERNEL = 0,       /* march kernel: 0 = global gathers (baseline), 1 = per-wave LDS staging (default),
+                                 2..5 = other LDS tile shapes for tuning (DESIGN.md "Kernels") */
+    VRM_OPT_SKIP_EMPTY = 1,   /* exact empty-space skipping, default 1: chunks whose texels all have alpha == 0 are not
+                                 sampled; they contribute exactly 0, so the image is bit-identical to 0 (tests) */
+    VRM_OPT_PROFILE = 2,      /* default 0; 1: record hipEvents around every march launch (vrm_profile_read) */
+    VRM_OPT_DIAGNOSTICS = 3   /* default 0; 1: also write per-pixel f32 colour, iteration counts and ray geometry */
 } vrm_option;
 VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
 VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);

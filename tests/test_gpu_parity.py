@@ -193,12 +193,16 @@ def test_empty_space_skipping_is_bit_exact(vr, orc):
                 rm.set_option(vr.OPT_KERNEL, k)
                 rm.set_option(vr.OPT_SKIP_EMPTY, s)
                 res[(k, s)] = draw(rm, vr, cam, 160, 120)
-            base = res[(1, 0)]
-            for key in [(0, 0), (1, 1)]:
-                assert np.array_equal(res[key]["rgba8"], base["rgba8"]), key
-                assert np.array_equal(res[key]["f32"].view(np.uint32), base["f32"].view(np.uint32)), key
-                assert np.array_equal(res[key]["iters"], base["iters"]), key
-                assert np.array_equal(res[key]["geo"].view(np.uint32), base["geo"].view(np.uint32)), key
+            base, skip, glob = res[(1, 0)], res[(1, 1)], res[(0, 0)]
+            assert np.array_equal(skip["rgba8"], base["rgba8"])
+            assert np.array_equal(skip["f32"].view(np.uint32), base["f32"].view(np.uint32))   # bit for bit
+            for other in (skip, glob):
+                assert np.array_equal(other["iters"], base["iters"])
+                assert np.array_equal(other["geo"].view(np.uint32), base["geo"].view(np.uint32))
+            # the global-gather variant forms the texel coordinate from the exact position, the LDS variant (in
+            # interior chunks) straight from dt: continuous arithmetic, equal to rounding
+            assert np.abs(glob["f32"] - base["f32"]).max() < F32_TOL
+            assert np.abs(glob["rgba8"].astype(int) - base["rgba8"].astype(int)).max() <= 1
     rm.close()
 
 

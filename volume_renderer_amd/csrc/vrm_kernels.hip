@@ -9,6 +9,8 @@
 //     operations are written explicitly;
 //   * filter / transfer function / blend are continuous, written with explicit FMAs and folded
 //     constants, and agree with the oracle to rounding.
+#include <type_traits>
+
 #include "vrm_device.h"
 
 #pragma clang fp contract(off)
@@ -122,7 +124,9 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         acc.cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
     } else if (ALPHA_ONLY) {
         acc.cr = __builtin_fmaf(w, a255, acc.cr); // r == g == b == a for scalar volumes
-    } else {
+    } else if (__builtin_amdgcn_ballot_w64(a255 != 0.0f) != 0ull) {
+        // a == 0 => alpha_src = 0 => w = 0 => the colour terms add exactly 0: filter r,g,b only when some
+        // lane of the wave has a non-zero alpha (wave-uniform branch, three quarters of the filter work)
         acc.cr = __builtin_fmaf(w, tri(0), acc.cr);
         acc.cg = __builtin_fmaf(w, tri(1), acc.cg);
         acc.cb = __builtin_fmaf(w, tri(2), acc.cb);
@@ -252,11 +256,14 @@ __device__ __forceinline__ float wave_max(float v)
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // global_load_dwordx4 only needs dword alignment
+
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int PX, int CAP, int K>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
-    static_assert(PX >= 4 && PX <= 64, "row pitch");
-    __shared__ uint32_t tile[CAP];
+    static_assert(PX >= 4 && PX <= 64 && PX % 4 == 0, "row pitch: a multiple of 4 texels (16-byte staging stores)");
+    __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     const VrmGridDev &g = P.grid;
     const uint32_t view = blockIdx.y;
     // Tile order.  The image is cut into 64x64-pixel super-blocks (8x8 wave tiles).  Workgroup b runs on the
@@ -291,10 +298,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     // per-step advance of a ray in texel space, bounded over the wave once: every chunk's box is then
     // [min start, max start] widened by k steps of it, for any k, without another reduction.  The 1 % slack
     // covers the drift of the running f32 dt sum (an ulp of dt per step, 0.4 % of a step at dt = 100).
-    float dlo[3], dhi[3];
+    float dlo[3], dhi[3], rs[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float du = ray.rd[a] * g.tex_scale[a] * (VRM_STEP_SIZE * 1.01f);
+        rs[a] = ray.rd[a] * g.tex_scale[a];
+        const float du = rs[a] * (VRM_STEP_SIZE * 1.01f);
         dlo[a] = fminf(wave_min(active ? du : __builtin_inff()), 0.0f);
         dhi[a] = fmaxf(wave_max(active ? du : -__builtin_inff()), 0.0f);
     }
@@ -355,21 +363,43 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             const int rows = ny * nz;
             const float inv_ny = 1.0f / (float)ny;
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
-            const bool lane_on = er < RPI && ex < nx;
             uint32_t seen = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
+            const int nx4 = (nx + 3) & ~3;
+            if (ilo[0] >= 0 && ilo[0] + nx4 <= (int)g.dim[0]) {
+                // rows lie inside the volume in x: 16 bytes per lane, PX/4 lanes per row, 64/(PX/4) rows per pass
+                constexpr int QPR = PX / 4, RPW = 64 / QPR;
+                const int q = (int)lane % QPR, r0 = (int)lane / QPR;
+                const bool lane_on = r0 < RPW && 4 * q < nx;
+                const uint32_t gx = (uint32_t)(ilo[0] + 4 * q);
+#pragma unroll 2
+                for (int row = r0; row < rows; row += RPW) {
+                    const int ez = (int)(((float)row + 0.5f) * inv_ny);
+                    const int ey = row - ez * ny;
+                    const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
+                    const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
+                    if (lane_on) {
+                        const u32x4_a4 w = *reinterpret_cast<const u32x4_a4 *>(g.vox + (((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx));
+                        *reinterpret_cast<u32x4 *>(&tile[row * PX + 4 * q]) = w;
+                        seen |= (w.x | w.y) | (w.z | w.w);
+                    }
+                }
+            } else {
+                // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
+                const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
+                const bool lane_on = er < RPI && ex < nx;
 #pragma unroll 4
-            for (int row = er; row < rows; row += RPI) {
-                // row -> (ey, ez): (row + 0.5)/ny is at least 0.5/ny away from an integer, far above f32 error
-                const int ez = (int)(((float)row + 0.5f) * inv_ny);
-                const int ey = row - ez * ny;
-                const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
-                if (lane_on) {
-                    const uint32_t w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
-                    tile[row * PX + ex] = w;
-                    seen |= w;
+                for (int row = er; row < rows; row += RPI) {
+                    // row -> (ey, ez): (row + 0.5)/ny is at least 0.5/ny away from an integer, far above f32 error
+                    const int ez = (int)(((float)row + 0.5f) * inv_ny);
+                    const int ey = row - ez * ny;
+                    const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
+                    const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
+                    if (lane_on) {
+                        const uint32_t w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
+                        tile[row * PX + ex] = w;
+                        seen |= w;
+                    }
                 }
             }
             if (SKIP) empty = __builtin_amdgcn_ballot_w64((seen >> 24) != 0u) == 0ull; // staged box is the exact touch set
@@ -396,44 +426,101 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         }
 
         // ---- K lockstep steps -------------------------------------------------------------------------
-        const int slice = ny * PX;
-        for (int j = 0; j < kk; ++j) {
-            if (active) {
-                if (DIAG) ++iters;
-                const float p0 = ray.ro[0] + ray.rd[0] * dt;
-                const float p1 = ray.ro[1] + ray.rd[1] * dt;
-                const float p2 = ray.ro[2] + ray.rd[2] * dt;
-                const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
-                                    (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
-                bool done = false;
-                if (inside) {
-                    if (DIAG) ++n_inside;
-                    const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
-                    const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
-                    const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
-                    const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
-                    uint32_t c[8];
-                    if (fits) {
-                        // the box holds floor(u) and floor(u)+1 of every in-box sample of the chunk by construction;
-                        // the clamps only keep a rounding surprise from reading another wave's... nothing: LDS is per wave
-                        const int lx = min(max((int)f0 - ilo[0], 0), nx - 2);
-                        const int ly = min(max((int)f1 - ilo[1], 0), ny - 2);
-                        const int lz = min(max((int)f2 - ilo[2], 0), nz - 2);
-                        const int a0 = (lz * ny + ly) * PX + lx;
-                        c[0] = tile[a0];             c[1] = tile[a0 + 1];
-                        c[2] = tile[a0 + PX];        c[3] = tile[a0 + PX + 1];
-                        c[4] = tile[a0 + slice];     c[5] = tile[a0 + slice + 1];
-                        c[6] = tile[a0 + slice + PX]; c[7] = tile[a0 + slice + PX + 1];
-                    } else {
-                        fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+        if (fits) {
+            // Texel coordinate relative to the staged box.  The sample POSITION p = ro + rd*dt and the in-box test
+            // must be the oracle's exact operation sequence, but they only matter where a sample can fall outside
+            // the box; the texel coordinate itself feeds continuous arithmetic only.  So a chunk whose whole box
+            // lies inside the volume with margin ("interior", the common case) skips p and the test and takes
+            // u = dt*(rd*scale) + (ro*scale + bias - box origin) in one FMA per axis.
+            bool interior = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float eps = 0.03f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
+                interior = interior && (slo[a] + (float)kk * dlo[a] - eps >= -0.5f) &&
+                           (shi[a] + (float)kk * dhi[a] + eps <= (float)g.dim[a] - 0.5f);
+            }
+            interior = uni(interior ? 1 : 0) != 0;
+            const float fpx = (float)PX, fsl = (float)(ny * PX);
+            const float cmx = (float)(nx - 2), cmy = (float)(ny - 2), cmz = (float)(nz - 2);
+            const int slice = ny * PX;
+            auto steps = [&](auto interior_c) {
+                constexpr bool INTERIOR = decltype(interior_c)::value;
+                float bl[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    bl[a] = (INTERIOR ? __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]) : g.tex_bias[a]) - (float)ilo[a];
+                for (int j = 0; j < kk; ++j) {
+                    if (active) {
+                        if (DIAG) ++iters;
+                        float u0, u1, u2;
+                        bool inside = true;
+                        if constexpr (INTERIOR) {
+                            u0 = __builtin_fmaf(dt, rs[0], bl[0]);
+                            u1 = __builtin_fmaf(dt, rs[1], bl[1]);
+                            u2 = __builtin_fmaf(dt, rs[2], bl[2]);
+                        } else {
+                            const float p0 = ray.ro[0] + ray.rd[0] * dt;
+                            const float p1 = ray.ro[1] + ray.rd[1] * dt;
+                            const float p2 = ray.ro[2] + ray.rd[2] * dt;
+                            inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
+                                     (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
+                            u0 = __builtin_fmaf(p0, g.tex_scale[0], bl[0]);
+                            u1 = __builtin_fmaf(p1, g.tex_scale[1], bl[1]);
+                            u2 = __builtin_fmaf(p2, g.tex_scale[2], bl[2]);
+                        }
+                        bool done = false;
+                        if (inside) {
+                            if (DIAG) ++n_inside;
+                            const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
+                            // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
+                            // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
+                            const float c0 = __builtin_amdgcn_fmed3f(f0, 0.0f, cmx), c1 = __builtin_amdgcn_fmed3f(f1, 0.0f, cmy),
+                                        c2 = __builtin_amdgcn_fmed3f(f2, 0.0f, cmz);
+                            const int a0 = (int)__builtin_fmaf(c2, fsl, __builtin_fmaf(c1, fpx, c0)); // exact: small integers
+                            uint32_t c[8];
+                            c[0] = tile[a0];              c[1] = tile[a0 + 1];
+                            c[2] = tile[a0 + PX];         c[3] = tile[a0 + PX + 1];
+                            c[4] = tile[a0 + slice];      c[5] = tile[a0 + slice + 1];
+                            c[6] = tile[a0 + slice + PX]; c[7] = tile[a0 + slice + PX + 1];
+                            done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                        }
+                        if (!done) {
+                            dt += VRM_STEP_SIZE;
+                            done = dt >= ray.t_max;
+                        }
+                        active = !done;
                     }
-                    done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
                 }
-                if (!done) {
-                    dt += VRM_STEP_SIZE;
-                    done = dt >= ray.t_max;
+            };
+            if (interior) steps(std::true_type{});
+            else steps(std::false_type{});
+        } else {
+            // box too large for the LDS tile (far-away camera: a pixel spans many voxels): gather from global memory
+            for (int j = 0; j < kk; ++j) {
+                if (active) {
+                    if (DIAG) ++iters;
+                    const float p0 = ray.ro[0] + ray.rd[0] * dt;
+                    const float p1 = ray.ro[1] + ray.rd[1] * dt;
+                    const float p2 = ray.ro[2] + ray.rd[2] * dt;
+                    const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
+                                        (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
+                    bool done = false;
+                    if (inside) {
+                        if (DIAG) ++n_inside;
+                        const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
+                        const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
+                        const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
+                        const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
+                        uint32_t c[8];
+                        fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+                        done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                    }
+                    if (!done) {
+                        dt += VRM_STEP_SIZE;
+                        done = dt >= ray.t_max;
+                    }
+                    active = !done;
                 }
-                active = !done;
             }
         }
         i += kk;
@@ -577,8 +664,20 @@ void launch_variant(const VrmMarchParams &p, uint32_t n_views, int variant, bool
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
     } else {
         const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, 20, 4096, 16>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, 20, 4096, 16>), grid, block, 0, stream, p);
+#define VRM_LDS(PXV, CAPV, KV)                                                                                   \
+    do {                                                                                                         \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, PXV, CAPV, KV>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, PXV, CAPV, KV>), grid, block, 0, stream, p);     \
+    } while (0)
+        // (row pitch, LDS words per wave, steps per chunk): LDS per wave sets the waves per CU (160 KB / CU)
+        switch (variant) {
+        case 2: VRM_LDS(16, 2048, 8); break;   //  8 KB -> 20 waves/CU
+        case 3: VRM_LDS(20, 2560, 8); break;   // 10 KB -> 16 waves/CU
+        case 4: VRM_LDS(20, 4096, 16); break;  // 16 KB -> 10 waves/CU
+        case 5: VRM_LDS(24, 6144, 24); break;  // 24 KB ->  6 waves/CU
+        default: VRM_LDS(20, 3072, 12); break; // 12 KB -> 13 waves/CU (variant 1, the default: profiles/r1/sweep.txt)
+        }
+#undef VRM_LDS
     }
 }
 
