@@ -242,17 +242,35 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
 // chunk.  The dt lattice, the sample positions and the in-box test are the same exact sequence as
 // in variant 0 / the oracle; only where the texels are read from differs.
 // ---------------------------------------------------------------------------------------------
+// Wave64 min/max on the VALU's data-parallel-primitive path (no LDS traffic, unlike __shfl): two quad
+// permutes, two row mirrors, then row_bcast:15 / row_bcast:31 carry the row results upwards; lane 63 ends up
+// with the reduction over all 64 lanes and is read back into an SGPR.  Must run with all lanes enabled
+// (inactive rays pass the identity), which is how the kernel calls it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
-    return v;
+    v = fminf(v, dpp_mov<0xB1, 0xF>(v));  // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_mov<0x4E, 0xF>(v));  // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_mov<0x141, 0xF>(v)); // row_half_mirror
+    v = fminf(v, dpp_mov<0x140, 0xF>(v)); // row_mirror
+    v = fminf(v, dpp_mov<0x142, 0xA>(v)); // row_bcast:15 into rows 1 and 3
+    v = fminf(v, dpp_mov<0x143, 0xC>(v)); // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x141, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x140, 0xF>(v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
