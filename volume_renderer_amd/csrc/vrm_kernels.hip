@@ -386,20 +386,26 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             const int nx4 = (nx + 3) & ~3;
             if (ilo[0] >= 0 && ilo[0] + nx4 <= (int)g.dim[0]) {
                 // rows lie inside the volume in x: 16 bytes per lane, PX/4 lanes per row, 64/(PX/4) rows per pass
+                // A lane keeps its (x quad, y row) and walks z: the per-pass address work is one add with a uniform
+                // z stride (the y clamp is per lane once, the z clamp is scalar).
                 constexpr int QPR = PX / 4, RPW = 64 / QPR;
-                const int q = (int)lane % QPR, r0 = (int)lane / QPR;
-                const bool lane_on = r0 < RPW && 4 * q < nx;
+                const int q = (int)lane % QPR, eyl = (int)lane / QPR;
                 const uint32_t gx = (uint32_t)(ilo[0] + 4 * q);
-#pragma unroll 2
-                for (int row = r0; row < rows; row += RPW) {
-                    const int ez = (int)(((float)row + 0.5f) * inv_ny);
-                    const int ey = row - ez * ny;
+                const size_t zstride = (size_t)g.dim[0] * g.dim[1];
+                for (int eb = 0; eb * RPW < ny; ++eb) {
+                    const int ey = eb * RPW + eyl;
+                    const bool lane_on = eyl < RPW && ey < ny && 4 * q < nx;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                    const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
-                    if (lane_on) {
-                        const u32x4_a4 w = *reinterpret_cast<const u32x4_a4 *>(g.vox + (((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx));
-                        *reinterpret_cast<u32x4 *>(&tile[row * PX + 4 * q]) = w;
-                        seen |= (w.x | w.y) | (w.z | w.w);
+                    const uint32_t *src = g.vox + ((size_t)gy * g.dim[0] + gx);
+                    uint32_t *dst = &tile[ey * PX + 4 * q];
+#pragma unroll 4
+                    for (int ez = 0; ez < nz; ++ez) {
+                        const int gz = min(max(ilo[2] + ez, 0), mxz); // uniform
+                        if (lane_on) {
+                            const u32x4_a4 w = *reinterpret_cast<const u32x4_a4 *>(src + (size_t)gz * zstride);
+                            *reinterpret_cast<u32x4 *>(dst + ez * (ny * PX)) = w;
+                            seen |= (w.x | w.y) | (w.z | w.w);
+                        }
                     }
                 }
             } else {
