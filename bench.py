@@ -41,7 +41,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the export rendered by the CPU baseline (at most)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU baseline after this much CPU-side wall time")
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "custom"],
+                    help="BASELINE.json configs[1..3]; C3 is the headline and the default; 'custom' takes --dim/--res/... as given")
+    ap.add_argument("--volume", default=None, choices=["rgba", "scalar"],
+                    help="rgba: f32 color(c,z,y,x) NetCDF-style; scalar: DAT-style density replicated to r=g=b=a")
     a = ap.parse_args()
+    presets = {"C2": dict(dim=256, res=512, xdiv=8, ydiv=9, volume="scalar"),     # 256^3 u8 DAT, 64 views, 512^2
+               "C3": dict(dim=512, res=1024, xdiv=16, ydiv=17, volume="rgba"),    # 512^3 f32 RGBA, 256 views, 1024^2
+               "C4": dict(dim=1024, res=2048, xdiv=16, ydiv=9, volume="scalar")}  # 1024^3 f32 scalar, 128 views, 2048^2
+    if a.config in presets:
+        for k, v in presets[a.config].items():
+            if k == "volume":
+                a.volume = a.volume or v
+            else:
+                setattr(a, k, v)
+    a.volume = a.volume or "rgba"
 
     import numpy as np
     import torch  # first: the HIP library then shares torch's libamdhip64 instead of loading a second runtime
@@ -70,7 +84,10 @@ def main():
     t0 = time.time()
     host_q = None
     if rank == 0:
-        host_q = synth.quantize_rgba8(synth.blobs_rgba_f32(dims))  # (v*255.0) as u8, loaders/netcdf.rs:54-57
+        if a.volume == "rgba":
+            host_q = synth.quantize_rgba8(synth.blobs_rgba_f32(dims))  # (v*255.0) as u8, loaders/netcdf.rs:54-57
+        else:
+            host_q = np.repeat(synth.blobs_scalar_u8(dims)[..., None], 4, axis=3)  # [b,b,b,b], loaders/dat.rs:74
         vol = torch.from_numpy(host_q).to(dev)
     else:
         vol = torch.empty((D, D, D, 4), dtype=torch.uint8, device=dev)
@@ -161,8 +178,19 @@ def main():
     b_alg_view = D * D * D * 4 + R * R * 4
     views_timed = len(my_cams) * a.steps
     achieved = (b_alg_view * views_timed / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else 0.0
+    # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3 around the process): the figure comes
+    # from the committed counter passes of the same workload (profiles/*/traffic.json: 2*FETCH_SIZE + WRITE_SIZE
+    # per view, gfx950 correction as in MI355X_MICROARCH.md), scaled to the views of one launch; null if none.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}"
+        if key in tj:
+            traffic = int(tj[key]["hbm_bytes_per_view"] * B)
+    except (OSError, ValueError, KeyError):
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "march kernel (variant %d)" % a.kernel, "launches": int(launches),
                 "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
                 "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B}
@@ -171,7 +199,8 @@ def main():
         "metric": "views/s", "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C3: {D}^3 float32 RGBA volume (blobs seed {synth.DEFAULT_SEED}, quantised to RGBA8 on ingest), "
+        "config": {"workload": f"{a.config}: {D}^3 " + ("float32 RGBA volume" if a.volume == "rgba" else "scalar (DAT-style) volume") +
+                               f" (blobs seed {synth.DEFAULT_SEED}, quantised to RGBA8 on ingest), "
                                f"{n_views}-view sphere export at {R}x{R}, radius {a.radius}, attenuation {a.attenuation}, "
                                f"transfer function {'on' if a.tf else 'off'}",
                    "volume": [D, D, D], "image": [R, R], "views": n_views, "parallelism": f"view-partitioned x{world}",
