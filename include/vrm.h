@@ -173,7 +173,8 @@ typedef enum vrm_option {
     VRM_OPT_SKIP_EMPTY = 1,   /* exact empty-space skipping, default 1: chunks whose texels all have alpha == 0 are not
                                  sampled; they contribute exactly 0, so the image is bit-identical to 0 (tests) */
     VRM_OPT_PROFILE = 2,      /* default 0; 1: record hipEvents around every march launch (vrm_profile_read) */
-    VRM_OPT_DIAGNOSTICS = 3   /* default 0; 1: also write per-pixel f32 colour, iteration counts and ray geometry */
+    VRM_OPT_DIAGNOSTICS = 3,  /* default 0; 1: also write per-pixel f32 colour, iteration counts and ray geometry */
+    VRM_OPT_CHUNK_STEPS = 4   /* default 0 = automatic; n: march steps per LDS-staged box (tuning, no effect on the image) */
 } vrm_option;
 VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
 VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);

@@ -25,11 +25,17 @@ def main():
     ap.add_argument("--scalar", action="store_true")
     ap.add_argument("--tf", action="store_true")
     ap.add_argument("--att", type=float, default=1.0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--xdiv", type=int, default=16)
+    ap.add_argument("--ydiv", type=int, default=17)
+    ap.add_argument("--ix", type=int, default=-1, help="only the views of this azimuth index")
+    ap.add_argument("--all", action="store_true", help="every view of the sphere, in launches of --views")
     a = ap.parse_args()
     D, R = a.dim, a.res
     rm = vr.RayMarcher(0, R, R)
     rm.set_option(vr.OPT_KERNEL, a.kernel)
     rm.set_option(vr.OPT_SKIP_EMPTY, a.skip)
+    rm.set_option(vr.OPT_CHUNK_STEPS, a.chunk)
     if a.scalar:
         s = synth.blobs_scalar_u8((D, D, D))
         rm.voxel_grid.upload_scalar(s.reshape(-1), (D, D, D), 1)
@@ -39,15 +45,41 @@ def main():
     rm.voxel_grid.update_voxel_grid_buffer()
     rm.voxel_grid.set_transfer_function_active(a.tf)
     rm.voxel_grid.update_transfer_function_buffer()
-    allv = vr.sphere_views(16, 17)
-    views = allv[:: max(1, len(allv) // a.views)][: a.views]
+    allv = vr.sphere_views(a.xdiv, a.ydiv)
+    if a.ix >= 0:
+        views = [v for v in allv if v[0] == a.ix][: a.views]   # one azimuth, every polar step
+    else:
+        views = allv[:: max(1, len(allv) // a.views)][: a.views]
     cam = vr.Camera(1.0)
-    csp = vr.CameraSphereController(17, 16, (0, 0, 0), 2.5)
+    csp = vr.CameraSphereController(a.ydiv, a.xdiv, (0, 0, 0), 2.5)
     cams = []
     for ix, iy in views:
         csp.current_index_x, csp.current_index_y = ix, iy
         csp.update_position(cam)
         cams.append(cam.uniform())
+    if a.all:
+        # the whole export in launches of --views views, per-launch times (view direction changes the cost)
+        cams = []
+        for ix, iy in allv:
+            csp.current_index_x, csp.current_index_y = ix, iy
+            csp.update_position(cam)
+            cams.append(cam.uniform())
+        imgs = [vr.Screenshotter(rm, R, R) for _ in range(a.views)]
+        n_ref = rm.count_reference_samples(cams, R, R)
+        rm.set_option(vr.OPT_PROFILE, 1)
+        for rep in range(a.reps):
+            per = []
+            for c0 in range(0, len(cams), a.views):
+                part = cams[c0:c0 + a.views]
+                rm.draw_batch(part, imgs[:len(part)])
+                rm.synchronize()
+                ms, n = rm.profile_read()
+                per.append(ms / len(part))
+            tot = sum(p * min(a.views, len(cams) - i * a.views) for i, p in enumerate(per))
+            print(f"kernel {a.kernel} skip {a.skip} chunk {a.chunk}: all {len(cams)} views {R}^2 of {D}^3: {tot:.1f} ms => "
+                  f"{tot / len(cams):.3f} ms/view, {n_ref / tot / 1e6:.1f} Gsamples/s; ms/view per launch: "
+                  + " ".join(f"{p:.2f}" for p in per), flush=True)
+        return
     imgs = [vr.Screenshotter(rm, R, R) for _ in cams]
     n_ref = rm.count_reference_samples(cams, R, R)
     rm.set_option(vr.OPT_PROFILE, 1)

@@ -11,8 +11,8 @@ import os
 import numpy as np
 
 from . import _ffi
-from ._ffi import (CameraUniform, GridUniform, TransferFunction, VrmError, OPT_DIAGNOSTICS, OPT_KERNEL, OPT_PROFILE,
-                   OPT_SKIP_EMPTY)
+from ._ffi import (CameraUniform, GridUniform, TransferFunction, VrmError, OPT_CHUNK_STEPS, OPT_DIAGNOSTICS, OPT_KERNEL,
+                   OPT_PROFILE, OPT_SKIP_EMPTY)
 
 __all__ = ["RayMarcher", "VoxelGrid", "Screenshotter", "Camera", "CameraSphereController", "SphereScreenshotManager",
            "CameraUniform", "TransferFunction", "GridUniform", "VrmError", "sphere_views"]

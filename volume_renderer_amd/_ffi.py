@@ -16,6 +16,7 @@ OPT_KERNEL = 0
 OPT_SKIP_EMPTY = 1
 OPT_PROFILE = 2
 OPT_DIAGNOSTICS = 3
+OPT_CHUNK_STEPS = 4
 
 
 class VrmError(RuntimeError):

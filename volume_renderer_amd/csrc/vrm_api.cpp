@@ -459,6 +459,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
         p->col_c[i] = ctx->tf.color_c[i];
     }
     p->use_tf = ctx->tf.use_transfer_function[0] != 0 ? 1u : 0u;
+    p->chunk_steps = (uint32_t)ctx->opt_chunk;
 }
 
 extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
@@ -592,6 +593,7 @@ extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
     case VRM_OPT_SKIP_EMPTY: ctx->opt_skip = value; break;
     case VRM_OPT_PROFILE: ctx->opt_profile = value; break;
     case VRM_OPT_DIAGNOSTICS: ctx->opt_diag = value; break;
+    case VRM_OPT_CHUNK_STEPS: ctx->opt_chunk = value < 0 ? 0 : (value > 256 ? 256 : value); break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;
@@ -605,6 +607,7 @@ extern "C" int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value)
     case VRM_OPT_SKIP_EMPTY: *value = ctx->opt_skip; break;
     case VRM_OPT_PROFILE: *value = ctx->opt_profile; break;
     case VRM_OPT_DIAGNOSTICS: *value = ctx->opt_diag; break;
+    case VRM_OPT_CHUNK_STEPS: *value = ctx->opt_chunk; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;

@@ -40,6 +40,7 @@ struct VrmMarchParams {
     float attenuation;   // voxel_grid.buffer[0] (wgsl:150)
     float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
     uint32_t use_tf;
+    uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 6 texels of depth)
 };
 
 // launchers implemented in vrm_kernels.hip

@@ -29,7 +29,7 @@ struct vrm_ctx {
     hipEvent_t views_free = nullptr;   // signalled when the last batch's descriptor upload was consumed
 
     // options
-    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0;
+    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0;
 
     // profiling (VRM_OPT_PROFILE)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -277,7 +277,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // global_load_dwordx4 only needs dword alignment
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int PX, int CAP, int K>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int PX, int CAP>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
     static_assert(PX >= 4 && PX <= 64 && PX % 4 == 0, "row pitch: a multiple of 4 texels (16-byte staging stores)");
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             shi[a] = wave_max(active ? ua : -__builtin_inff());
         }
         // largest chunk length (K, K/2, ..., 1) whose box fits the LDS tile
-        int kk = min(K, VRM_MAX_STEP_AMOUNT - i);
+        int kk = min((int)P.chunk_steps, VRM_MAX_STEP_AMOUNT - i);
         int ilo[3], ihi[3], nx, ny, nz;
         bool none, fits;
         for (;;) {
@@ -681,25 +681,31 @@ inline uint32_t stream_blocks(size_t n)
 }
 
 template <bool A, bool T, bool D>
-void launch_variant(const VrmMarchParams &p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
+void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
 {
     if (variant == 0) {
         const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
     } else {
         const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
-#define VRM_LDS(PXV, CAPV, KV)                                                                                   \
-    do {                                                                                                         \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, PXV, CAPV, KV>), grid, block, 0, stream, p); \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, PXV, CAPV, KV>), grid, block, 0, stream, p);     \
+        // texels a ray advances per step (the step is 0.001 world units whatever the resolution, wgsl:126)
+        float tps = 0.0f;
+        for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
+        if (variant == 1) variant = tps > 0.75f ? 4 : 1; // >= 1024^3: deeper boxes per step, take the 16 KB tile
+#define VRM_LDS(PXV, CAPV, DEPTH)                                                                              \
+    do {                                                                                                       \
+        /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                   \
+        if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, PXV, CAPV>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, PXV, CAPV>), grid, block, 0, stream, p);       \
     } while (0)
-        // (row pitch, LDS words per wave, steps per chunk): LDS per wave sets the waves per CU (160 KB / CU)
+        // (row pitch, LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
         switch (variant) {
-        case 2: VRM_LDS(16, 2048, 8); break;   //  8 KB -> 20 waves/CU
-        case 3: VRM_LDS(20, 2560, 8); break;   // 10 KB -> 16 waves/CU
-        case 4: VRM_LDS(20, 4096, 16); break;  // 16 KB -> 10 waves/CU
-        case 5: VRM_LDS(24, 6144, 24); break;  // 24 KB ->  6 waves/CU
-        default: VRM_LDS(20, 3072, 12); break; // 12 KB -> 13 waves/CU (variant 1, the default: profiles/r1/sweep.txt)
+        case 2: VRM_LDS(16, 2048, 4.0f); break;  //  8 KB -> 20 waves/CU
+        case 3: VRM_LDS(20, 2560, 4.0f); break;  // 10 KB -> 16 waves/CU
+        case 4: VRM_LDS(20, 4096, 16.0f); break; // 16 KB -> 10 waves/CU
+        case 5: VRM_LDS(24, 6144, 16.0f); break; // 24 KB ->  6 waves/CU
+        default: VRM_LDS(20, 3072, 9.0f); break; // 12 KB -> 13 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
