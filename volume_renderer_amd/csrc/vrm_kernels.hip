@@ -277,10 +277,13 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // global_load_dwordx4 only needs dword alignment
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int PX, int CAP>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
-    static_assert(PX >= 4 && PX <= 64 && PX % 4 == 0, "row pitch: a multiple of 4 texels (16-byte staging stores)");
+    // LDS tile layout, chosen per chunk: rows along x with pitch = the box's x extent rounded up to 4 texels
+    // (16-byte staging stores), slices along z with pitch = ny * pitch rounded up to 4 (mod 8) words, which keeps
+    // the 32-lane gather groups spread over the 32 banks for every view direction (DESIGN.md "LDS layout").
+    constexpr int PX_MAX = 32;
     __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     const VrmGridDev &g = P.grid;
     const uint32_t view = blockIdx.y;
@@ -309,10 +312,6 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
 
-    // staging lane map: PX lanes along x per row, RPI rows per pass
-    constexpr int RPI = 64 / PX;
-    const int ex = (int)lane % PX, er = (int)lane / PX;
-
     // per-step advance of a ray in texel space, bounded over the wave once: every chunk's box is then
     // [min start, max start] widened by k steps of it, for any k, without another reduction.  The 1 % slack
     // covers the drift of the running f32 dt sum (an ulp of dt per step, 0.4 % of a step at dt = 100).
@@ -339,7 +338,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         }
         // largest chunk length (K, K/2, ..., 1) whose box fits the LDS tile
         int kk = min((int)P.chunk_steps, VRM_MAX_STEP_AMOUNT - i);
-        int ilo[3], ihi[3], nx, ny, nz;
+        int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
         bool none, fits;
         for (;;) {
 #pragma unroll
@@ -352,7 +351,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             }
             nx = ihi[0] - ilo[0] + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
             none = nx < 2 || ny < 2 || nz < 2;                         // whole chunk lies outside the box
-            fits = !none && nx <= PX && (long long)ny * nz * PX <= (long long)CAP;
+            pitch = (nx + 3) & ~3;
+            slice = ny * pitch;
+            slice += (slice & 4) ? 0 : 4;
+            fits = !none && pitch <= PX_MAX && (long long)nz * slice <= (long long)CAP;
             if (fits || none || kk == 1) break;
             kk >>= 1;
         }
@@ -383,45 +385,48 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
             uint32_t seen = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
-            const int nx4 = (nx + 3) & ~3;
-            if (ilo[0] >= 0 && ilo[0] + nx4 <= (int)g.dim[0]) {
-                // rows lie inside the volume in x: 16 bytes per lane, PX/4 lanes per row, 64/(PX/4) rows per pass
+            // lane / n for a wave-uniform n <= 64: (lane + 0.5)/n is at least 0.5/n away from an integer, far above f32 error
+            if (ilo[0] >= 0 && ilo[0] + pitch <= (int)g.dim[0]) {
+                // rows lie inside the volume in x: 16 bytes per lane, pitch/4 lanes per row, 64/(pitch/4) rows per pass.
                 // A lane keeps its (x quad, y row) and walks z: the per-pass address work is one add with a uniform
                 // z stride (the y clamp is per lane once, the z clamp is scalar).
-                constexpr int QPR = PX / 4, RPW = 64 / QPR;
-                const int q = (int)lane % QPR, eyl = (int)lane / QPR;
+                const int qpr = pitch >> 2;
+                const int rpw = (int)(64.0f / (float)qpr);
+                const int eyl = (int)(((float)lane + 0.5f) * (1.0f / (float)qpr)), q = (int)lane - eyl * qpr;
                 const uint32_t gx = (uint32_t)(ilo[0] + 4 * q);
                 const size_t zstride = (size_t)g.dim[0] * g.dim[1];
-                for (int eb = 0; eb * RPW < ny; ++eb) {
-                    const int ey = eb * RPW + eyl;
-                    const bool lane_on = eyl < RPW && ey < ny && 4 * q < nx;
+                for (int eb = 0; eb * rpw < ny; ++eb) {
+                    const int ey = eb * rpw + eyl;
+                    const bool lane_on = eyl < rpw && ey < ny;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                     const uint32_t *src = g.vox + ((size_t)gy * g.dim[0] + gx);
-                    uint32_t *dst = &tile[ey * PX + 4 * q];
+                    uint32_t *dst = &tile[ey * pitch + 4 * q];
 #pragma unroll 4
                     for (int ez = 0; ez < nz; ++ez) {
                         const int gz = min(max(ilo[2] + ez, 0), mxz); // uniform
                         if (lane_on) {
                             const u32x4_a4 w = *reinterpret_cast<const u32x4_a4 *>(src + (size_t)gz * zstride);
-                            *reinterpret_cast<u32x4 *>(dst + ez * (ny * PX)) = w;
+                            *reinterpret_cast<u32x4 *>(dst + ez * slice) = w;
                             seen |= (w.x | w.y) | (w.z | w.w);
                         }
                     }
                 }
             } else {
                 // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
+                const int rpi = (int)(64.0f / (float)pitch);
+                const int er = (int)(((float)lane + 0.5f) * (1.0f / (float)pitch)), ex = (int)lane - er * pitch;
                 const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
-                const bool lane_on = er < RPI && ex < nx;
+                const bool lane_on = er < rpi && ex < nx;
 #pragma unroll 4
-                for (int row = er; row < rows; row += RPI) {
-                    // row -> (ey, ez): (row + 0.5)/ny is at least 0.5/ny away from an integer, far above f32 error
+                for (int row = er; row < rows; row += rpi) {
+                    // row -> (ey, ez)
                     const int ez = (int)(((float)row + 0.5f) * inv_ny);
                     const int ey = row - ez * ny;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                     const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
                     if (lane_on) {
                         const uint32_t w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
-                        tile[row * PX + ex] = w;
+                        tile[ez * slice + ey * pitch + ex] = w;
                         seen |= w;
                     }
                 }
@@ -464,9 +469,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                            (shi[a] + (float)kk * dhi[a] + eps <= (float)g.dim[a] - 0.5f);
             }
             interior = uni(interior ? 1 : 0) != 0;
-            const float fpx = (float)PX, fsl = (float)(ny * PX);
+            const float fpx = (float)pitch, fsl = (float)slice;
             const float cmx = (float)(nx - 2), cmy = (float)(ny - 2), cmz = (float)(nz - 2);
-            const int slice = ny * PX;
             auto steps = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
                 float bl[3];
@@ -501,11 +505,12 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             const float c0 = __builtin_amdgcn_fmed3f(f0, 0.0f, cmx), c1 = __builtin_amdgcn_fmed3f(f1, 0.0f, cmy),
                                         c2 = __builtin_amdgcn_fmed3f(f2, 0.0f, cmz);
                             const int a0 = (int)__builtin_fmaf(c2, fsl, __builtin_fmaf(c1, fpx, c0)); // exact: small integers
+                            const int a1 = a0 + pitch, a2 = a0 + slice, a3 = a2 + pitch;
                             uint32_t c[8];
-                            c[0] = tile[a0];              c[1] = tile[a0 + 1];
-                            c[2] = tile[a0 + PX];         c[3] = tile[a0 + PX + 1];
-                            c[4] = tile[a0 + slice];      c[5] = tile[a0 + slice + 1];
-                            c[6] = tile[a0 + slice + PX]; c[7] = tile[a0 + slice + PX + 1];
+                            c[0] = tile[a0]; c[1] = tile[a0 + 1];
+                            c[2] = tile[a1]; c[3] = tile[a1 + 1];
+                            c[4] = tile[a2]; c[5] = tile[a2 + 1];
+                            c[6] = tile[a3]; c[7] = tile[a3 + 1];
                             done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
                         }
                         if (!done) {
@@ -692,20 +697,20 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         float tps = 0.0f;
         for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
         if (variant == 1) variant = tps > 0.75f ? 4 : 1; // >= 1024^3: deeper boxes per step, take the 16 KB tile
-#define VRM_LDS(PXV, CAPV, DEPTH)                                                                              \
+#define VRM_LDS(CAPV, DEPTH)                                                                                   \
     do {                                                                                                       \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                   \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, PXV, CAPV>), grid, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, PXV, CAPV>), grid, block, 0, stream, p);       \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV>), grid, block, 0, stream, p);       \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV>), grid, block, 0, stream, p);           \
     } while (0)
-        // (row pitch, LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
+        // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
         switch (variant) {
-        case 2: VRM_LDS(16, 2048, 4.0f); break;  //  8 KB -> 20 waves/CU
-        case 3: VRM_LDS(20, 2560, 4.0f); break;  // 10 KB -> 16 waves/CU
-        case 4: VRM_LDS(20, 4096, 16.0f); break; // 16 KB -> 10 waves/CU
-        case 5: VRM_LDS(24, 6144, 16.0f); break; // 24 KB ->  6 waves/CU
-        default: VRM_LDS(20, 3072, 9.0f); break; // 12 KB -> 13 waves/CU (variant 1, the default)
+        case 2: VRM_LDS(2048, 6.0f); break;  //  8 KB -> 20 waves/CU
+        case 3: VRM_LDS(2560, 8.0f); break;  // 10 KB -> 16 waves/CU
+        case 4: VRM_LDS(4096, 16.0f); break; // 16 KB -> 10 waves/CU
+        case 5: VRM_LDS(6144, 16.0f); break; // 24 KB ->  6 waves/CU
+        default: VRM_LDS(3072, 9.0f); break; // 12 KB -> 13 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
