@@ -696,7 +696,6 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         // texels a ray advances per step (the step is 0.001 world units whatever the resolution, wgsl:126)
         float tps = 0.0f;
         for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
-        if (variant == 1) variant = tps > 0.75f ? 4 : 1; // >= 1024^3: deeper boxes per step, take the 16 KB tile
 #define VRM_LDS(CAPV, DEPTH)                                                                                   \
     do {                                                                                                       \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                   \
@@ -705,12 +704,14 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV>), grid, block, 0, stream, p);           \
     } while (0)
         // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
+        // 10 KB is the measured optimum for 256^3 .. 1024^3 volumes (tools/prof_workload.py --all); the others are
+        // kept selectable (VRM_OPT_KERNEL) for A/B runs
         switch (variant) {
-        case 2: VRM_LDS(2048, 6.0f); break;  //  8 KB -> 20 waves/CU
-        case 3: VRM_LDS(2560, 8.0f); break;  // 10 KB -> 16 waves/CU
-        case 4: VRM_LDS(4096, 16.0f); break; // 16 KB -> 10 waves/CU
-        case 5: VRM_LDS(6144, 16.0f); break; // 24 KB ->  6 waves/CU
-        default: VRM_LDS(3072, 9.0f); break; // 12 KB -> 13 waves/CU (variant 1, the default)
+        case 2: VRM_LDS(2048, 6.0f); break;  //  8 KB -> 20 waves/CU by LDS (the ~92 VGPRs allow 20)
+        case 3: VRM_LDS(2304, 8.0f); break;  //  9 KB -> 17 waves/CU
+        case 4: VRM_LDS(3072, 9.0f); break;  // 12 KB -> 13 waves/CU
+        case 5: VRM_LDS(4096, 16.0f); break; // 16 KB -> 10 waves/CU
+        default: VRM_LDS(2560, 8.0f); break; // 10 KB -> 16 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
