@@ -41,12 +41,81 @@ __global__ void __launch_bounds__(256) probe(float *out, unsigned long long *cyc
                                "v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel_hi:[1,0,0]\n"
                                "v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel_hi:[1,0,0]\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(c));)
+        } else if (MODE == 5) { // byte -> biased float through one byte permute (selector in %9)
+            REP16(asm volatile("v_perm_b32 %0, %8, %0, %9\n v_perm_b32 %1, %8, %1, %9\n v_perm_b32 %2, %8, %2, %9\n v_perm_b32 %3, %8, %3, %9\n"
+                               "v_perm_b32 %4, %8, %4, %9\n v_perm_b32 %5, %8, %5, %9\n v_perm_b32 %6, %8, %6, %9\n v_perm_b32 %7, %8, %7, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(0x07060004u));)
+        } else if (MODE == 6) { // packed f16 FMA (two halves per lane)
+            REP16(asm volatile("v_pk_fma_f16 %0, %0, %8, %9\n v_pk_fma_f16 %1, %1, %8, %9\n v_pk_fma_f16 %2, %2, %8, %9\n v_pk_fma_f16 %3, %3, %8, %9\n"
+                               "v_pk_fma_f16 %4, %4, %8, %9\n v_pk_fma_f16 %5, %5, %8, %9\n v_pk_fma_f16 %6, %6, %8, %9\n v_pk_fma_f16 %7, %7, %8, %9\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(c));)
+        } else if (MODE == 7) { // bit-field extract (the integer alternative to cvt_ubyte)
+            REP16(asm volatile("v_bfe_u32 %0, %8, 8, 8\n v_bfe_u32 %1, %8, 16, 8\n v_bfe_u32 %2, %8, 8, 8\n v_bfe_u32 %3, %8, 16, 8\n"
+                               "v_bfe_u32 %4, %8, 8, 8\n v_bfe_u32 %5, %8, 16, 8\n v_bfe_u32 %6, %8, 8, 8\n v_bfe_u32 %7, %8, 16, 8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w));)
+        } else if (MODE == 8) { // plain f32 add (VOP2)
+            REP16(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                               "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (MODE == 9) { // cvt_ubyte through SDWA on a VOP2 add: a + float? no -- u8 dot: v_dot4_u32_u8
+            REP16(asm volatile("v_dot4_u32_u8 %0, %8, %9, %0\n v_dot4_u32_u8 %1, %8, %9, %1\n v_dot4_u32_u8 %2, %8, %9, %2\n v_dot4_u32_u8 %3, %8, %9, %3\n"
+                               "v_dot4_u32_u8 %4, %8, %9, %4\n v_dot4_u32_u8 %5, %8, %9, %5\n v_dot4_u32_u8 %6, %8, %9, %6\n v_dot4_u32_u8 %7, %8, %9, %7\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(0x01010101u));)
+        } else if (MODE == 10) { // byte (as a denormal bit pattern) * 2^127 through SDWA: convert and scale in one VOP2
+            REP16(asm volatile("v_mul_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                               "v_mul_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(0x7f000000u));)
+        } else if (MODE == 11) { // byte - byte in the denormal domain
+            REP16(asm volatile("v_sub_f32_sdwa %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n"
+                               "v_sub_f32_sdwa %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                               "v_sub_f32_sdwa %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n"
+                               "v_sub_f32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                               "v_sub_f32_sdwa %4, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n"
+                               "v_sub_f32_sdwa %5, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+                               "v_sub_f32_sdwa %6, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n"
+                               "v_sub_f32_sdwa %7, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(0x04030201u));)
+        } else if (MODE == 12) { // FMA with a denormal multiplicand (the difference above) and a 2^127-scaled weight
+            REP16(asm volatile("v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n"
+                               "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(0x00000037u), "v"(0x7e800000u));)
+        } else if (MODE == 13) { // the other half-rate suspects of the inner loop
+            REP16(asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n"
+                               "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(w), "v"(c));)
+        } else if (MODE == 14) { // f32 multiply (VOP2)
+            REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                               "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p5.x + p6.x + p7.x;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// out[l] = byte1(w) * 2^-22, out[64+l] = (byte3 - byte1) * 2^-24, out[128+l] = their sum through one FMA
+__global__ void sdwa_values(float *out)
+{
+    const unsigned l = threadIdx.x;
+    const unsigned w = (((l * 101u + 7u) & 0xffu) << 24) | (((l * 37u + 11u) & 0xffu) << 8) | 0x00aa0055u;
+    float m, d, f;
+    const unsigned two127 = 0x7f000000u, two125 = 0x7e000000u;
+    asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(m) : "v"(w), "v"(two127));
+    asm volatile("v_sub_f32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(d) : "v"(w));
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(f) : "v"(d), "v"(two125), "v"(m));
+    float dm;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(dm) : "v"(d), "v"(two125));
+    out[l] = m;
+    out[64 + l] = dm;
+    out[128 + l] = f;
 }
 
 template <int MODE>
@@ -89,6 +158,36 @@ int main()
         run<2>("v_cvt_f32_ubyteN", w);
         run<3>("v_exp_f32", w);
         run<4>("v_fma_mix_f32(f16 src)", w);
+        run<5>("v_perm_b32", w);
+        run<6>("v_pk_fma_f16", w);
+        run<7>("v_bfe_u32", w);
+        run<8>("v_add_f32", w);
+        run<9>("v_dot4_u32_u8", w);
+        run<10>("v_mul_f32_sdwa(byte)", w);
+        run<11>("v_sub_f32_sdwa(bytes)", w);
+        run<12>("v_fma_f32(denormal src)", w);
+        run<13>("floor/cvt_i32/med3/add_u32", w);
+        run<14>("v_mul_f32", w);
+    }
+    // value check of the denormal-domain byte arithmetic
+    {
+        float *d;
+        (void)hipMalloc(&d, 64 * 3 * sizeof(float));
+        sdwa_values<<<1, 64>>>(d);
+        float h[192];
+        (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) {
+            const unsigned b1 = (l * 37u + 11u) & 0xffu, b3 = (l * 101u + 7u) & 0xffu;
+            const float want_mul = (float)b1 * 0x1p-22f;                       // byte1 * 2^-149 * 2^127
+            const float want_sub = ((float)b3 - (float)b1) * 0x1p-22f * 0.25f; // (byte3 - byte1) * 2^-149 * (0.25 * 2^127)
+            const float want_fma = want_sub + want_mul;
+            if (h[l] != want_mul || h[64 + l] != want_sub || h[128 + l] != want_fma) {
+                if (bad < 4) printf("lane %d: mul %g (want %g) sub %g (want %g) fma %g (want %g)\n", l, h[l], want_mul, h[64 + l], want_sub, h[128 + l], want_fma);
+                ++bad;
+            }
+        }
+        printf("sdwa denormal-domain values: %s (%d mismatches of 64)\n", bad ? "MISMATCH" : "exact", bad);
     }
     return 0;
 }

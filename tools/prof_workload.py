@@ -49,7 +49,9 @@ def main():
     if a.ix >= 0:
         views = [v for v in allv if v[0] == a.ix][: a.views]   # one azimuth, every polar step
     else:
-        views = allv[:: max(1, len(allv) // a.views)][: a.views]
+        # a spread over polar AND azimuth steps (a plain stride of 8 or 16 would keep hitting the same azimuths,
+        # i.e. only axis-aligned views, which are the cheap ones)
+        views = [allv[(i * 37) % len(allv)] for i in range(min(a.views, len(allv)))]
     cam = vr.Camera(1.0)
     csp = vr.CameraSphereController(a.ydiv, a.xdiv, (0, 0, 0), 2.5)
     cams = []
