@@ -72,6 +72,9 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     if (ctx->occ) HIP_TRY(hipFree(ctx->occ));
     ctx->occ = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 7) / 8) * ((y + 7) / 8) * ((z + 7) / 8)));
+    if (ctx->bricks) HIP_TRY(hipFree(ctx->bricks));
+    ctx->bricks = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
     return VRM_OK;
@@ -86,6 +89,7 @@ extern "C" int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
     HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
     HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
+    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
     ctx->scalar = false;
     ctx->attenuation = 1.0f;   // grid.rs:100,197
     tf_defaults(&ctx->tf);     // grid.rs:198
@@ -143,6 +147,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
     }
     if (ctx->vox) (void)hipFree(ctx->vox);
     if (ctx->occ) (void)hipFree(ctx->occ);
+    if (ctx->bricks) (void)hipFree(ctx->bricks);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     if (ctx->views_dev) (void)hipFree(ctx->views_dev);
     if (ctx->views_host) (void)hipHostFree(ctx->views_host);
@@ -155,6 +160,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
 static int grid_finish_upload(vrm_ctx *ctx)
 {
     HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
+    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->flag_dev, 0, 4, ctx->stream));
     HIP_TRY(vrm_launch_detect_nonscalar(ctx->vox, ctx->vox_words, ctx->flag_dev, ctx->stream));
     uint32_t flag = 1;
@@ -436,6 +442,9 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     g.vox = ctx->vox;
     g.scalar = ctx->scalar ? 1u : 0u;
     g.occ = ctx->occ;
+    g.bricks = ctx->bricks;
+    g.nbx = (ctx->dim[0] + 3) / 4;
+    g.nby = (ctx->dim[1] + 3) / 4;
     for (int i = 0; i < 3; ++i) {
         g.dim[i] = ctx->dim[i];
         g.occ_dim[i] = (ctx->dim[i] + 7) / 8;

@@ -18,6 +18,7 @@ struct vrm_ctx {
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere
     uint8_t *occ = nullptr;  // max alpha per 8^3 cell, rebuilt whenever the voxels change
+    uint32_t *bricks = nullptr; // the same voxels in 4x4x2-texel bricks of one 128-byte line each (staging source)
     float attenuation = 1.0f;
     vrm_transfer_function tf;
     uint32_t *flag_dev = nullptr; // 1 word scratch for detect_nonscalar

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     // LDS tile layout, chosen per chunk: rows along x with pitch = the box's x extent rounded up to 4 texels
     // (16-byte staging stores), slices along z with pitch = ny * pitch rounded up to 4 (mod 8) words, which keeps
     // the 32-lane gather groups spread over the 32 banks for every view direction (DESIGN.md "LDS layout").
-    constexpr int PX_MAX = 32;
+    constexpr int PX_MAX = 64; // one staging instruction holds at least one whole row
     __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     const VrmGridDev &g = P.grid;
     const uint32_t view = blockIdx.y;
@@ -349,14 +349,16 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 ilo[a] = uni((int)floorf(lo));
                 ihi[a] = uni((int)floorf(hi) + 1);
             }
+            none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
+            // rows start on a 4-texel boundary: the staging loads are whole 16-byte quads of the bricked volume
+            if (ilo[0] >= 0) ilo[0] &= ~3;
             nx = ihi[0] - ilo[0] + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
-            none = nx < 2 || ny < 2 || nz < 2;                         // whole chunk lies outside the box
             pitch = (nx + 3) & ~3;
             slice = ny * pitch;
             slice += (slice & 4) ? 0 : 4;
             fits = !none && pitch <= PX_MAX && (long long)nz * slice <= (long long)CAP;
             if (fits || none || kk == 1) break;
-            kk >>= 1;
+            kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
         if (!fits && !none) kk = min(8, VRM_MAX_STEP_AMOUNT - i);      // global-gather fallback chunk
 
@@ -387,30 +389,36 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
             // lane / n for a wave-uniform n <= 64: (lane + 0.5)/n is at least 0.5/n away from an integer, far above f32 error
             if (ilo[0] >= 0 && ilo[0] + pitch <= (int)g.dim[0]) {
-                // rows lie inside the volume in x: 16 bytes per lane, pitch/4 lanes per row, 64/(pitch/4) rows per pass.
-                // A lane keeps its (x quad, y row) and walks z: the per-pass address work is one add with a uniform
-                // z stride (the y clamp is per lane once, the z clamp is scalar).
+                // rows lie inside the volume in x.  Source: the bricked copy; transport: LDS-DMA (global_load_lds_dwordx4),
+                // 16 bytes per lane straight into the tile, no VGPR round trip, no ds_write, every load of the box in
+                // flight at once.  One instruction fills up to 64 consecutive quads of one z slice: lane -> (x quad q,
+                // row ey) with LDS word ey*pitch + 4q = 4*lane, exactly the lane-linear image the DMA writes.  The per-lane
+                // source offset (brick column and row) is the same for every slice; the slice offset is scalar.
                 const int qpr = pitch >> 2;
                 const int rpw = (int)(64.0f / (float)qpr);
                 const int eyl = (int)(((float)lane + 0.5f) * (1.0f / (float)qpr)), q = (int)lane - eyl * qpr;
-                const uint32_t gx = (uint32_t)(ilo[0] + 4 * q);
-                const size_t zstride = (size_t)g.dim[0] * g.dim[1];
+                const uint32_t bx = ((uint32_t)ilo[0] >> 2) + (uint32_t)q;
+                const size_t zslab = (size_t)g.nbx * g.nby * 128u;   // bytes per brick layer (2 slices)
                 for (int eb = 0; eb * rpw < ny; ++eb) {
                     const int ey = eb * rpw + eyl;
                     const bool lane_on = eyl < rpw && ey < ny;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                    const uint32_t *src = g.vox + ((size_t)gy * g.dim[0] + gx);
-                    uint32_t *dst = &tile[ey * pitch + 4 * q];
-#pragma unroll 4
+                    const uint32_t voff = (((gy >> 2) * g.nbx + bx) * 8u + (gy & 3u)) * 16u;
+                    uint32_t *drow = &tile[eb * rpw * pitch];
                     for (int ez = 0; ez < nz; ++ez) {
-                        const int gz = min(max(ilo[2] + ez, 0), mxz); // uniform
-                        if (lane_on) {
-                            const u32x4_a4 w = *reinterpret_cast<const u32x4_a4 *>(src + (size_t)gz * zstride);
-                            *reinterpret_cast<u32x4 *>(dst + ez * slice) = w;
-                            seen |= (w.x | w.y) | (w.z | w.w);
-                        }
+                        const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz); // uniform
+                        const char *zbase = reinterpret_cast<const char *>(g.bricks) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
+#ifdef VRM_ABLATE_STAGE
+                        if (lane_on && P.chunk_steps == 9999u) // timing experiment: never true, no staging traffic at all
+#else
+                        if (lane_on)
+#endif
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zbase + voff),
+                                                             (__attribute__((address_space(3))) void *)(drow + ez * slice), 16, 0, 0);
                     }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                seen = 0xff000000u; // the staged texels do not pass through registers: emptiness comes from the occupancy grid alone
             } else {
                 // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
                 const int rpi = (int)(64.0f / (float)pitch);
@@ -659,6 +667,29 @@ __global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__r
     if (threadIdx.x == 0) occ[cell] = (uint8_t)m;
 }
 
+// x-fastest voxels -> 4x4x2-texel bricks (VrmGridDev::bricks).  One thread per 16-byte quad of a brick, output
+// fully coalesced; texels beyond the volume (dims not multiples of 4,4,2) replicate the edge and are never sampled.
+__global__ void __launch_bounds__(256) build_bricks_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
+                                                           uint32_t nbx, uint32_t nby, size_t n_quads, u32x4 *__restrict__ bricks)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += stride) {
+        const size_t brick = i >> 3;
+        const uint32_t local = (uint32_t)i & 7u;
+        const size_t bz = brick / ((size_t)nbx * nby), r = brick - bz * nbx * nby;
+        const uint32_t by = (uint32_t)(r / nbx), bx = (uint32_t)(r - (size_t)by * nbx);
+        const uint32_t y = min(by * 4u + (local & 3u), Y - 1u), z = min((uint32_t)bz * 2u + (local >> 2), Z - 1u);
+        const uint32_t *row = vox + ((size_t)z * Y + y) * X;
+        const uint32_t x = bx * 4u;
+        u32x4 w;
+        w.x = row[min(x, X - 1u)];
+        w.y = row[min(x + 1u, X - 1u)];
+        w.z = row[min(x + 2u, X - 1u)];
+        w.w = row[min(x + 3u, X - 1u)];
+        bricks[i] = w;
+    }
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(uint32_t *dst, size_t n, uint32_t value)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -718,6 +749,15 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
 }
 
 } // namespace
+
+hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *bricks, hipStream_t stream)
+{
+    const uint32_t nbx = (dim[0] + 3) / 4, nby = (dim[1] + 3) / 4, nbz = (dim[2] + 1) / 2;
+    const size_t n_quads = (size_t)nbx * nby * nbz * 8;
+    hipLaunchKernelGGL(build_bricks_kernel, dim3(stream_blocks(n_quads)), dim3(256), 0, stream, vox, dim[0], dim[1], dim[2], nbx, nby,
+                       n_quads, reinterpret_cast<u32x4 *>(bricks));
+    return hipGetLastError();
+}
 
 hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
 {
