@@ -312,42 +312,72 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
 
-    // per-step advance of a ray in texel space, bounded over the wave once: every chunk's box is then
-    // [min start, max start] widened by k steps of it, for any k, without another reduction.  The 1 % slack
-    // covers the drift of the running f32 dt sum (an ulp of dt per step, 0.4 % of a step at dt = 100).
-    float dlo[3], dhi[3], rs[3];
+    // Per-step advance of a ray in texel space.  The 1 % slack covers the drift of the running f32 dt sum (an ulp
+    // of dt per step, 0.4 % of a step at dt = 100).
+    float rs[3], du[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         rs[a] = ray.rd[a] * g.tex_scale[a];
-        const float du = rs[a] * (VRM_STEP_SIZE * 1.01f);
-        dlo[a] = fminf(wave_min(active ? du : __builtin_inff()), 0.0f);
-        dhi[a] = fmaxf(wave_max(active ? du : -__builtin_inff()), 0.0f);
+        du[a] = rs[a] * (VRM_STEP_SIZE * 1.01f);
     }
-
-    int i = 0;
-    while (i < VRM_MAX_STEP_AMOUNT) {
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-
-        // ---- texel-space bounding box of this chunk, over the active rays ------------------------
-        float slo[3], shi[3];
+    // Front alignment.  Rays start on the entry faces of the box, so "the same number of steps for every ray" keeps
+    // the wave's samples on a copy of those faces: seen at a grazing angle an 8x8-pixel tile is spread over 40+
+    // texels along the rays and no chunk ever fits the tile.  Instead the wave advances a plane perpendicular to its
+    // major axis m: per chunk a lane takes as many steps (0..K) as bring it up to the common plane, so the box is
+    // the tile's cross-section times the chunk depth whatever the entry geometry.  Which lane takes which step in
+    // which chunk does not change any lane's own dt sequence: the image is bit-identical.
+    int m_axis = 0;
+    float sgn = 1.0f, smax = 0.0f;
+    bool aligned;
+    {
+        float amax[3], amin[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float ua = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
-            slo[a] = wave_min(active ? ua : __builtin_inff());
-            shi[a] = wave_max(active ? ua : -__builtin_inff());
+            amax[a] = wave_max(active ? du[a] : -__builtin_inff());
+            amin[a] = wave_min(active ? du[a] : __builtin_inff());
         }
-        // largest chunk length (K, K/2, ..., 1) whose box fits the LDS tile
-        int kk = min((int)P.chunk_steps, VRM_MAX_STEP_AMOUNT - i);
+        float best = -1.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float mag = fmaxf(amax[a], -amin[a]);
+            if (mag > best) { best = mag; m_axis = a; sgn = amax[a] >= -amin[a] ? 1.0f : -1.0f; smax = mag; }
+        }
+        // every active lane must move forward along m at a comparable rate (always true for a perspective tile of a
+        // sensible image; an 8x8-pixel image with a 90-degree field of view falls back to lockstep chunks)
+        const float slowest = sgn > 0.0f ? (m_axis == 0 ? amin[0] : m_axis == 1 ? amin[1] : amin[2])
+                                         : -(m_axis == 0 ? amax[0] : m_axis == 1 ? amax[1] : amax[2]);
+        aligned = slowest > 0.25f * smax;
+    }
+    const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
+    const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
+    int steps_left = VRM_MAX_STEP_AMOUNT; // wgsl:139: at most 5000 iterations per ray
+
+    for (;;) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+
+        // ---- this chunk: steps per lane and the texel-space bounding box of everything they touch ----
+        float ua[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+        const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
+        const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
+        int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane
+        int n_lane;                  // steps of this lane in this chunk
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
+        float blo[3], bhi[3];
         bool none, fits;
         for (;;) {
+            // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
+            const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
+            n_lane = active ? min(min((int)fminf(fmaxf(ahead, 0.0f), (float)kk), kk), steps_left) : 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test
-                const float lo = fmaxf(slo[a] + (float)kk * dlo[a] - 0.01f, -1.0f);
-                const float hi = fminf(shi[a] + (float)kk * dhi[a] + 0.01f, (float)g.dim[a] - 0.5f);
-                ilo[a] = uni((int)floorf(lo));
-                ihi[a] = uni((int)floorf(hi) + 1);
+                const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
+                blo[a] = wave_min(n_lane > 0 ? fminf(ua[a], ue) : __builtin_inff()) - 0.01f;
+                bhi[a] = wave_max(n_lane > 0 ? fmaxf(ua[a], ue) : -__builtin_inff()) + 0.01f;
+                ilo[a] = uni((int)floorf(fmaxf(blo[a], -1.0f)));
+                ihi[a] = uni((int)floorf(fminf(bhi[a], (float)g.dim[a] - 0.5f)) + 1);
             }
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-texel boundary: the staging loads are whole 16-byte quads of the bricked volume
@@ -360,7 +390,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             if (fits || none || kk == 1) break;
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
-        if (!fits && !none) kk = min(8, VRM_MAX_STEP_AMOUNT - i);      // global-gather fallback chunk
+        if (!fits && !none) { // global-gather fallback chunk: lockstep, 8 steps
+            kk = 8;
+            n_lane = active ? min(8, steps_left) : 0;
+        }
 
         // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
         // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
@@ -447,7 +480,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         if (empty) {
             // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
             for (int j = 0; j < kk; ++j) {
-                if (active) {
+                if (j < n_lane && active) {
                     if (DIAG) {
                         ++iters;
                         const float p0 = ray.ro[0] + ray.rd[0] * dt, p1 = ray.ro[1] + ray.rd[1] * dt, p2 = ray.ro[2] + ray.rd[2] * dt;
@@ -455,14 +488,14 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                                      (p1 < g.box_max[1]) & (p2 < g.box_max[2])) ? 1u : 0u;
                     }
                     dt += VRM_STEP_SIZE;
-                    active = !(dt >= ray.t_max);
+                    --steps_left;
+                    active = !(dt >= ray.t_max) && steps_left > 0;
                 }
             }
-            i += kk;
             continue;
         }
 
-        // ---- K lockstep steps -------------------------------------------------------------------------
+        // ---- the chunk's steps: lane l takes n_lane of them -------------------------------------------
         if (fits) {
             // Texel coordinate relative to the staged box.  The sample POSITION p = ro + rd*dt and the in-box test
             // must be the oracle's exact operation sequence, but they only matter where a sample can fall outside
@@ -473,8 +506,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float eps = 0.03f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-                interior = interior && (slo[a] + (float)kk * dlo[a] - eps >= -0.5f) &&
-                           (shi[a] + (float)kk * dhi[a] + eps <= (float)g.dim[a] - 0.5f);
+                interior = interior && (blo[a] - eps >= -0.5f) && (bhi[a] + eps <= (float)g.dim[a] - 0.5f);
             }
             interior = uni(interior ? 1 : 0) != 0;
             const float fpx = (float)pitch, fsl = (float)slice;
@@ -486,7 +518,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 for (int a = 0; a < 3; ++a)
                     bl[a] = (INTERIOR ? __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]) : g.tex_bias[a]) - (float)ilo[a];
                 for (int j = 0; j < kk; ++j) {
-                    if (active) {
+                    if (j < n_lane && active) {
                         if (DIAG) ++iters;
                         float u0, u1, u2;
                         bool inside = true;
@@ -525,7 +557,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             dt += VRM_STEP_SIZE;
                             done = dt >= ray.t_max;
                         }
-                        active = !done;
+                        --steps_left;
+                        active = !done && steps_left > 0;
                     }
                 }
             };
@@ -534,7 +567,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         } else {
             // box too large for the LDS tile (far-away camera: a pixel spans many voxels): gather from global memory
             for (int j = 0; j < kk; ++j) {
-                if (active) {
+                if (j < n_lane && active) {
                     if (DIAG) ++iters;
                     const float p0 = ray.ro[0] + ray.rd[0] * dt;
                     const float p1 = ray.ro[1] + ray.rd[1] * dt;
@@ -556,11 +589,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                         dt += VRM_STEP_SIZE;
                         done = dt >= ray.t_max;
                     }
-                    active = !done;
+                    --steps_left;
+                    active = !done && steps_left > 0;
                 }
             }
         }
-        i += kk;
     }
     finish_colour<ALPHA_ONLY, USE_TF>(acc);
     if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
