@@ -441,11 +441,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     for (int ez = 0; ez < nz; ++ez) {
                         const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz); // uniform
                         const char *zbase = reinterpret_cast<const char *>(g.bricks) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
-#ifdef VRM_ABLATE_STAGE
-                        if (lane_on && P.chunk_steps == 9999u) // timing experiment: never true, no staging traffic at all
-#else
                         if (lane_on)
-#endif
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zbase + voff),
                                                              (__attribute__((address_space(3))) void *)(drow + ez * slice), 16, 0, 0);
                     }
@@ -488,10 +484,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                                      (p1 < g.box_max[1]) & (p2 < g.box_max[2])) ? 1u : 0u;
                     }
                     dt += VRM_STEP_SIZE;
-                    --steps_left;
-                    active = !(dt >= ray.t_max) && steps_left > 0;
+                    active = !(dt >= ray.t_max);
                 }
             }
+            steps_left -= n_lane; // a lane that stopped early is inactive anyway
+            active = active && steps_left > 0;
             continue;
         }
 
@@ -557,8 +554,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             dt += VRM_STEP_SIZE;
                             done = dt >= ray.t_max;
                         }
-                        --steps_left;
-                        active = !done && steps_left > 0;
+                        active = !done;
                     }
                 }
             };
@@ -589,11 +585,12 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                         dt += VRM_STEP_SIZE;
                         done = dt >= ray.t_max;
                     }
-                    --steps_left;
-                    active = !done && steps_left > 0;
+                    active = !done;
                 }
             }
         }
+        steps_left -= n_lane; // a lane that stopped early is inactive anyway
+        active = active && steps_left > 0;
     }
     finish_colour<ALPHA_ONLY, USE_TF>(acc);
     if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
