@@ -71,7 +71,7 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
     if (ctx->occ) HIP_TRY(hipFree(ctx->occ));
     ctx->occ = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 7) / 8) * ((y + 7) / 8) * ((z + 7) / 8)));
+    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 3) / 4)));
     if (ctx->bricks) HIP_TRY(hipFree(ctx->bricks));
     ctx->bricks = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
@@ -447,7 +447,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     g.nby = (ctx->dim[1] + 3) / 4;
     for (int i = 0; i < 3; ++i) {
         g.dim[i] = ctx->dim[i];
-        g.occ_dim[i] = (ctx->dim[i] + 7) / 8;
+        g.occ_dim[i] = (ctx->dim[i] + 3) / 4;
         g.box_min[i] = u.box_min[i];
         g.box_size[i] = u.box_size[i];
         g.box_max[i] = u.box_min[i] + u.box_size[i]; // wgsl:202,250

@@ -84,7 +84,33 @@ __device__ __forceinline__ uint32_t unorm8(float v)
     return (uint32_t)floorf(v * 255.0f + 0.5f);
 }
 
-__device__ __forceinline__ float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+constexpr float T22 = 4194304.0f; // 2^22 = 2^149 / 2^127
+
+// byte K of w, as a float in units of 2^-22: the byte read through SDWA is the denormal K * 2^-149, times 2^127
+template <int K>
+__device__ __forceinline__ float byte_scaled(uint32_t w)
+{
+    static_assert(K >= 0 && K < 4, "byte index");
+    float r;
+    const float two127 = 0x1p127f;
+    if constexpr (K == 0) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(two127));
+    if constexpr (K == 1) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(two127));
+    if constexpr (K == 2) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(two127));
+    if constexpr (K == 3) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "v"(two127));
+    return r;
+}
+
+// (byte K of b) - (byte K of a) as the exact denormal difference * 2^-149 (multiply by a 2^127-scaled weight to use it)
+template <int K>
+__device__ __forceinline__ float byte_diff(uint32_t b, uint32_t a)
+{
+    float r;
+    if constexpr (K == 0) asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(b), "v"(a));
+    if constexpr (K == 1) asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(b), "v"(a));
+    if constexpr (K == 2) asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(b), "v"(a));
+    if constexpr (K == 3) asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
 
 struct Accum {
     float cr, cg, cb, alpha; // colour in 0..255 texel units while marching when the TF is off
@@ -96,17 +122,24 @@ template <bool ALPHA_ONLY, bool USE_TF>
 __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
                                       Accum &acc)
 {
-    auto tri = [&](int k) -> float {
-        const float a00 = ub(c[0], k), a10 = ub(c[2], k), a01 = ub(c[4], k), a11 = ub(c[6], k);
-        const float c00 = __builtin_fmaf(wx, ub(c[1], k) - a00, a00);
-        const float c10 = __builtin_fmaf(wx, ub(c[3], k) - a10, a10);
-        const float c01 = __builtin_fmaf(wx, ub(c[5], k) - a01, a01);
-        const float c11 = __builtin_fmaf(wx, ub(c[7], k) - a11, a11);
+    // Byte k of an RGBA8 word read through SDWA is the f32 denormal k * 2^-149: one instruction gives the difference
+    // of two texels' channels, exact, and an FMA with the 2^127-scaled weight brings it back into the normal range
+    // (tools/probes/valu_probe.hip: values exact, the FMA runs at full rate with a denormal operand).  Per x-lerp
+    // that is sub_sdwa + mul_sdwa + fma instead of two conversions, a subtraction and an FMA.  The filter works in
+    // units of 2^-22 texel levels; T22 undoes it.
+    const float wxs = wx * 0x1p127f;
+    auto tri = [&](auto kc) -> float {
+        constexpr int k = decltype(kc)::value;
+        const float a00 = byte_scaled<k>(c[0]), a10 = byte_scaled<k>(c[2]), a01 = byte_scaled<k>(c[4]), a11 = byte_scaled<k>(c[6]);
+        const float c00 = __builtin_fmaf(byte_diff<k>(c[1], c[0]), wxs, a00);
+        const float c10 = __builtin_fmaf(byte_diff<k>(c[3], c[2]), wxs, a10);
+        const float c01 = __builtin_fmaf(byte_diff<k>(c[5], c[4]), wxs, a01);
+        const float c11 = __builtin_fmaf(byte_diff<k>(c[7], c[6]), wxs, a11);
         const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
         const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
         return __builtin_fmaf(wz, c1 - c0, c0);
     };
-    const float a255 = tri(3);
+    const float a255 = tri(std::integral_constant<int, 3>{}) * T22;
     // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a255 * kexp), a255 = filtered alpha in 0..255
     const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
     const float om = 1.0f - acc.alpha;
@@ -127,9 +160,10 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     } else if (__builtin_amdgcn_ballot_w64(a255 != 0.0f) != 0ull) {
         // a == 0 => alpha_src = 0 => w = 0 => the colour terms add exactly 0: filter r,g,b only when some
         // lane of the wave has a non-zero alpha (wave-uniform branch, three quarters of the filter work)
-        acc.cr = __builtin_fmaf(w, tri(0), acc.cr);
-        acc.cg = __builtin_fmaf(w, tri(1), acc.cg);
-        acc.cb = __builtin_fmaf(w, tri(2), acc.cb);
+        // (accumulated in units of 2^-22 texel levels, finish_colour() rescales)
+        acc.cr = __builtin_fmaf(w, tri(std::integral_constant<int, 0>{}), acc.cr);
+        acc.cg = __builtin_fmaf(w, tri(std::integral_constant<int, 1>{}), acc.cg);
+        acc.cb = __builtin_fmaf(w, tri(std::integral_constant<int, 2>{}), acc.cb);
     }
     acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
     return acc.alpha >= 1.0f;
@@ -139,10 +173,16 @@ template <bool ALPHA_ONLY, bool USE_TF>
 __device__ __forceinline__ void finish_colour(Accum &acc)
 {
     if (!USE_TF) {
-        const float s = 1.0f / 255.0f;
-        acc.cr *= s;
-        if (ALPHA_ONLY) { acc.cg = acc.cr; acc.cb = acc.cr; }
-        else { acc.cg *= s; acc.cb *= s; }
+        if (ALPHA_ONLY) {
+            acc.cr *= 1.0f / 255.0f;
+            acc.cg = acc.cr;
+            acc.cb = acc.cr;
+        } else {
+            const float s = T22 * (1.0f / 255.0f); // colours were accumulated in units of 2^-22 texel levels
+            acc.cr *= s;
+            acc.cg *= s;
+            acc.cb *= s;
+        }
     }
 }
 
@@ -401,14 +441,22 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         bool empty = none;
         if (SKIP && !none && (fits || kk <= 8)) {
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const int c0x = max(ilo[0], 0) >> 3, c0y = max(ilo[1], 0) >> 3, c0z = max(ilo[2], 0) >> 3;
-            const int ncx = (min(ihi[0], mxx) >> 3) - c0x + 1, ncy = (min(ihi[1], mxy) >> 3) - c0y + 1,
-                      ncz = (min(ihi[2], mxz) >> 3) - c0z + 1;
-            if (ncx <= 4 && ncy <= 4 && ncz <= 4) {
-                const int cx = (int)lane & 3, cy = ((int)lane >> 2) & 3, cz = (int)lane >> 4;
+            const int c0x = max(ilo[0], 0) >> 2, c0y = max(ilo[1], 0) >> 2, c0z = max(ilo[2], 0) >> 2;
+            const int ncx = (min(ihi[0], mxx) >> 2) - c0x + 1, ncy = (min(ihi[1], mxy) >> 2) - c0y + 1,
+                      ncz = (min(ihi[2], mxz) >> 2) - c0z + 1;
+            const int ncxy = ncx * ncy, nc = ncxy * ncz;
+            if (nc <= 128) { // up to two 4^3-texel cells per lane
+                const float inv_xy = 1.0f / (float)ncxy, inv_x = 1.0f / (float)ncx;
                 bool occ = false;
-                if (cx < ncx && cy < ncy && cz < ncz)
-                    occ = g.occ[((size_t)(c0z + cz) * g.occ_dim[1] + (size_t)(c0y + cy)) * g.occ_dim[0] + (size_t)(c0x + cx)] != 0;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int c = (int)lane + 64 * r;
+                    if (c < nc) {
+                        const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
+                        const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
+                        occ |= g.occ[((size_t)(c0z + cz) * g.occ_dim[1] + (size_t)(c0y + cy)) * g.occ_dim[0] + (size_t)(c0x + cx)] != 0;
+                    }
+                }
                 empty = __builtin_amdgcn_ballot_w64(occ) == 0ull;
             }
         }
@@ -507,7 +555,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             }
             interior = uni(interior ? 1 : 0) != 0;
             const float fpx = (float)pitch, fsl = (float)slice;
-            const float cmx = (float)(nx - 2), cmy = (float)(ny - 2), cmz = (float)(nz - 2);
+            const float amax = (float)((nz - 2) * slice + (ny - 2) * pitch + (nx - 2)); // word address of the last corner cell
             auto steps = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
                 float bl[3];
@@ -539,9 +587,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
-                            const float c0 = __builtin_amdgcn_fmed3f(f0, 0.0f, cmx), c1 = __builtin_amdgcn_fmed3f(f1, 0.0f, cmy),
-                                        c2 = __builtin_amdgcn_fmed3f(f2, 0.0f, cmz);
-                            const int a0 = (int)__builtin_fmaf(c2, fsl, __builtin_fmaf(c1, fpx, c0)); // exact: small integers
+                            const float af = __builtin_fmaf(f2, fsl, __builtin_fmaf(f1, fpx, f0)); // exact: small integers
+                            const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax);
                             const int a1 = a0 + pitch, a2 = a0 + slice, a3 = a2 + pitch;
                             uint32_t c[8];
                             c[0] = tile[a0]; c[1] = tile[a0 + 1];
@@ -678,23 +725,32 @@ __global__ void __launch_bounds__(256) quantize_scalar_kernel(const uint8_t *__r
     }
 }
 
-// max alpha of every 8x8x8-voxel cell (one wave per cell): the look-up behind exact empty-space skipping
+// max alpha of every 4x4x4-voxel cell: the look-up behind exact empty-space skipping.  One wave per 8x8x8-voxel
+// region = 2x2x2 cells; lane (lx, ly) walks z, then the 4x4 lanes of a cell column are reduced by xor shuffles.
 __global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
-                                                             uint32_t cx_n, uint32_t cy_n, uint8_t *__restrict__ occ)
+                                                             uint32_t rx_n, uint32_t ry_n, uint32_t ox_n, uint32_t oy_n,
+                                                             uint32_t oz_n, uint8_t *__restrict__ occ)
 {
-    const uint32_t cell = blockIdx.x;
-    const uint32_t cz = cell / (cx_n * cy_n), r = cell - cz * cx_n * cy_n, cy = r / cx_n, cx = r - cy * cx_n;
+    const uint32_t reg = blockIdx.x;
+    const uint32_t rz = reg / (rx_n * ry_n), r = reg - rz * rx_n * ry_n, ry = r / rx_n, rx = r - ry * rx_n;
     const uint32_t lx = threadIdx.x & 7u, ly = threadIdx.x >> 3;
-    const uint32_t x = cx * 8u + lx, y = cy * 8u + ly;
-    uint32_t m = 0;
+    const uint32_t x = rx * 8u + lx, y = ry * 8u + ly;
+    uint32_t m[2] = {0, 0};
     if (x < X && y < Y)
         for (uint32_t k = 0; k < 8u; ++k) {
-            const uint32_t z = cz * 8u + k;
-            if (z < Z) m = max(m, vox[((size_t)z * Y + y) * X + x] >> 24);
+            const uint32_t z = rz * 8u + k;
+            if (z < Z) m[k >> 2] = max(m[k >> 2], vox[((size_t)z * Y + y) * X + x] >> 24);
         }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if (threadIdx.x == 0) occ[cell] = (uint8_t)m;
+    for (int h = 0; h < 2; ++h) {
+        uint32_t v = m[h];
+        v = max(v, (uint32_t)__shfl_xor((int)v, 1, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 2, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 8, 64));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+        const uint32_t cx = rx * 2u + (lx >> 2), cy = ry * 2u + (ly >> 2), cz = rz * 2u + (uint32_t)h;
+        if ((lx & 3u) == 0 && (ly & 3u) == 0 && cx < ox_n && cy < oy_n && cz < oz_n) occ[((size_t)cz * oy_n + cy) * ox_n + cx] = (uint8_t)v;
+    }
 }
 
 // x-fastest voxels -> 4x4x2-texel bricks (VrmGridDev::bricks).  One thread per 16-byte quad of a brick, output
@@ -791,8 +847,9 @@ hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], u
 
 hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
 {
-    const uint32_t cx = (dim[0] + 7) / 8, cy = (dim[1] + 7) / 8, cz = (dim[2] + 7) / 8;
-    hipLaunchKernelGGL(build_occupancy_kernel, dim3(cx * cy * cz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], cx, cy, occ);
+    const uint32_t rx = (dim[0] + 7) / 8, ry = (dim[1] + 7) / 8, rz = (dim[2] + 7) / 8;
+    hipLaunchKernelGGL(build_occupancy_kernel, dim3(rx * ry * rz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], rx, ry,
+                       (dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4, occ);
     return hipGetLastError();
 }
 
