@@ -165,6 +165,29 @@ VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, floa
 /* loaders/dat.rs:10-82: parse `ObjectFileName/Resolution/Format`, read the RAW next to it, upload. */
 VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
 
+/* ---- evaluation (the DiffDVR loop around the path) ---------------------------- */
+
+/* compare_to_netcdf_rmse (compare/netcdf.rs:8-75): RMSE between the loaded grid and a `color(c,z,y,x)` f32
+ * volume of the same dimensions (4 channels, channel-major, x fastest -- the NetCDF variable as stored).  Per
+ * voxel (alpha/255 - color[3])^2 and, unless density_only, the transfer-function colour of alpha (the context's
+ * three colours, breakpoint 0.5, whether or not the TF is switched on, netcdf.rs:41-61) against color[0..2];
+ * mean over voxels * (1 or 4), square root.  Terms are formed in f32 as the reference forms them; the sum is f64
+ * (the reference's one sequential f32 sum loses digits beyond ~10^7 voxels, see tests). */
+VRM_API int vrm_compare_volume_f32(vrm_ctx *ctx, const float *color_czyx, int density_only, float *out_rmse);
+VRM_API int vrm_compare_volume_f32_device(vrm_ctx *ctx, const float *color_czyx_device, int density_only, float *out_rmse);
+
+/* skimage.metrics.mean_squared_error on two uint8 images (scripts/similarity.py:59-61) is SSD / count; these
+ * return the exact integer sum of squared differences, of two rendered images (device side, same size; count =
+ * 4*w*h) or of two host arrays of n bytes.  rmse = sqrt(mse), psnr = 10 log10(255^2 / mse) (similarity.py:62-63). */
+VRM_API int vrm_image_ssd(vrm_image *a, vrm_image *b, uint64_t *out_ssd, uint64_t *out_count);
+VRM_API int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t n, uint64_t *out_ssd);
+
+/* skimage.io.imread (similarity.py:59-60) for the files this path writes and reads: 8-bit non-interlaced
+ * gray / gray+alpha / RGB / RGBA PNG.  Always sets width, height, channels; with pixels == NULL that is all
+ * (size query), otherwise decodes width*height*channels bytes, rows top to bottom, into pixels[capacity]. */
+VRM_API int vrm_png_read(const char *path, uint32_t *width, uint32_t *height, uint32_t *channels, uint8_t *pixels,
+                         size_t capacity);
+
 /* ---- build extensions (no reference counterpart) --------------------------------------------- */
 
 typedef enum vrm_option {

@@ -59,6 +59,9 @@ def lib():
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_geometry.argtypes = [f32p, u32p, ctypes.c_uint32, ctypes.c_uint32, f32p]
         L.orc_geometry.restype = None
+        L.orc_compare_volume.argtypes = [u8p, f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, f32p, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_double)]
+        L.orc_compare_volume.restype = ctypes.c_float
         _lib = L
     return _lib
 
@@ -175,3 +178,17 @@ def geometry(cam36, dims_xyz, width, height):
     out = np.zeros((height, width, 8), dtype=np.float32)
     lib().orc_geometry(_p(cam, ctypes.c_float), _p(dims, ctypes.c_uint32), width, height, _p(out, ctypes.c_float))
     return out
+
+
+def compare_volume(voxels_zyxc, data_czyx, tf_colors=DEFAULT_TF_COLORS, density_only=False):
+    """compare_to_netcdf_rmse (compare/netcdf.rs:8-75) -> (rmse as the reference's f32 running sum gives it,
+    the same with the sum carried in f64)."""
+    v = np.ascontiguousarray(voxels_zyxc, dtype=np.uint8)
+    Z, Y, X, _ = v.shape
+    d = np.ascontiguousarray(data_czyx, dtype=np.float32)
+    assert d.shape == (4, Z, Y, X), d.shape
+    tf9 = np.ascontiguousarray(np.asarray(tf_colors, dtype=np.float32)[:, :3]).reshape(9)
+    f64 = ctypes.c_double()
+    r = lib().orc_compare_volume(_p(v, ctypes.c_uint8), _p(d, ctypes.c_float), X, Y, Z, _p(tf9, ctypes.c_float),
+                                 1 if density_only else 0, ctypes.byref(f64))
+    return float(r), float(f64.value)

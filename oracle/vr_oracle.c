@@ -572,6 +572,56 @@ ORC_API void orc_geometry(const float cam36[36], const uint32_t dims[3], uint32_
     }
 }
 
+/* ---- compare/netcdf.rs:8-83: voxel-space RMSE between a grid and a color(c,z,y,x) f32 volume ------------------
+ * Loop order (x outer, y, z inner), the single running f32 sum, powi(.,2) as a product, remap() and mix() with the
+ * reference's operation order, the mean over x*y*z*amount_channels and the final f32 sqrt are all the reference's.
+ * tf9 = color_a.rgb, color_b.rgb, color_c.rgb (grid.rs:285-287).  *out_f64 (may be NULL) receives the same
+ * quantity with the sum carried in f64, which is what the GPU reduction computes. */
+static float cmp_remap(float value, float min1, float max1, float min2, float max2) /* netcdf.rs:81-83 */
+{
+    return min2 + (value - min1) * (max2 - min2) / (max1 - min1);
+}
+static float cmp_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; } /* netcdf.rs:77-79 */
+
+ORC_API float orc_compare_volume(const uint8_t *voxels, const float *data, uint32_t X, uint32_t Y, uint32_t Z,
+                                 const float tf9[9], int density_only, double *out_f64)
+{
+    const size_t n = (size_t)X * Y * Z;
+    float rmse = 0.0f;
+    double sum64 = 0.0;
+    int amount_channels = 1;
+    for (uint32_t x = 0; x < X; ++x)
+        for (uint32_t y = 0; y < Y; ++y)
+            for (uint32_t z = 0; z < Z; ++z) {
+                const size_t i = ((size_t)z * Y + y) * X + x;                 /* grid.rs:211, data[[c,z,y,x]] */
+                const float alpha = (float)voxels[4 * i + 3] / 255.0f;        /* netcdf.rs:31 */
+                float t = alpha - data[3 * n + i];
+                t = t * t;
+                rmse += t;                                                     /* netcdf.rs:32 */
+                sum64 += (double)t;
+                if (!density_only) {
+                    float s[3], e[3], ar;
+                    if (alpha < 0.5f) {
+                        for (int k = 0; k < 3; ++k) { s[k] = tf9[k]; e[k] = tf9[3 + k]; }
+                        ar = cmp_remap(alpha, 0.0f, 0.5f, 0.0f, 1.0f);
+                    } else {
+                        for (int k = 0; k < 3; ++k) { s[k] = tf9[3 + k]; e[k] = tf9[6 + k]; }
+                        ar = cmp_remap(alpha, 0.5f, 1.0f, 0.0f, 1.0f);
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        float d = cmp_mix(s[k], e[k], ar) - data[(size_t)k * n + i];
+                        d = d * d;
+                        rmse += d;                                             /* netcdf.rs:62-64 */
+                        sum64 += (double)d;
+                    }
+                    amount_channels = 4;
+                }
+            }
+    if (out_f64) *out_f64 = sqrt(sum64 / ((double)n * (double)amount_channels));
+    const float mean = rmse / (float)(n * (size_t)amount_channels);           /* netcdf.rs:73 */
+    return sqrtf(mean);
+}
+
 ORC_API int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -59,3 +59,13 @@ def image_metrics(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     mse = float(np.mean(d * d))
     return {"max": int(np.abs(d).max()), "rmse_lsb": mse ** 0.5, "rmse_norm": mse ** 0.5 / 255.0}
+
+
+@pytest.fixture
+def rm1(vr):
+    """One RayMarcher with the default kernel configuration (tests that do not depend on the march variant)."""
+    if not have_gpu():
+        pytest.skip("no /dev/kfd: GPU tests only run on the GPU box (-m gpu)")
+    r = vr.RayMarcher(0, 256, 256)
+    yield r
+    r.close()

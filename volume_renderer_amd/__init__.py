@@ -297,6 +297,32 @@ class RayMarcher:
         self.voxel_grid.attenuation = 1.0
         self.voxel_grid.transfer_function_colors = VoxelGrid._default_tf()
 
+    def compare_to_netcdf_rmse(self, color_czyx, density_only):
+        """compare::netcdf::compare_to_netcdf_rmse (compare/netcdf.rs:8-75) against an in-memory `color(c,z,y,x)` f32 array."""
+        d = _f32(color_czyx)
+        X, Y, Z = self.voxel_grid.dimensions
+        if d.size != 4 * X * Y * Z:
+            raise ValueError(f"expected color(4,{Z},{Y},{X}), got {d.shape}")
+        out = ctypes.c_float()
+        _ffi.check(_ffi.lib().vrm_compare_volume_f32(self._h, d.ctypes.data, 1 if density_only else 0, ctypes.byref(out)))
+        return out.value
+
+    def ssd_u8(self, a, b):
+        """Exact sum of squared differences of two uint8 arrays (GPU reduction); mse = ssd / a.size (similarity.py:61)."""
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        if a.shape != b.shape:
+            raise ValueError(f"shapes differ: {a.shape} vs {b.shape}")
+        out = ctypes.c_uint64()
+        _ffi.check(_ffi.lib().vrm_ssd_u8(self._h, a.ctypes.data, b.ctypes.data, a.size, ctypes.byref(out)))
+        return out.value
+
+    def image_ssd(self, img_a, img_b):
+        """SSD of two rendered images on the device -> (ssd, number of channel values)."""
+        ssd, cnt = ctypes.c_uint64(), ctypes.c_uint64()
+        _ffi.check(_ffi.lib().vrm_image_ssd(img_a._h, img_b._h, ctypes.byref(ssd), ctypes.byref(cnt)))
+        return ssd.value, cnt.value
+
     def export_sphere(self, x_div, y_div, radius, out_dir, origin=(0.0, 0.0, 0.0), part=0, n_parts=1):
         """"Screenshot All" (sphere_screenshot_manager.rs:23-73, state.rs:391-397)."""
         org = _f32(origin)

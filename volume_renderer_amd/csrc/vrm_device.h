@@ -60,3 +60,9 @@ hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sam
 hipError_t vrm_launch_fill(uint32_t *dst, size_t n_words, uint32_t value, hipStream_t stream);
 // sets *flag_dev to 1 if some voxel has r,g,b not all equal to a (i.e. the grid is not "scalar")
 hipError_t vrm_launch_detect_nonscalar(const uint32_t *vox, size_t n_voxels, uint32_t *flag_dev, hipStream_t stream);
+// evaluation reductions: `blocks` = vrm_reduce_blocks(n); `partial` holds one value per block, summed by the caller
+uint32_t vrm_reduce_blocks(size_t n_items);
+hipError_t vrm_launch_compare_volume(const uint32_t *vox, const float *data_czyx, size_t n_voxels, bool density_only,
+                                     const float tf9[9], double *partial, uint32_t blocks, hipStream_t stream);
+hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_words, size_t rows, size_t pitch_a, size_t pitch_b,
+                             unsigned long long *partial, uint32_t blocks, hipStream_t stream);

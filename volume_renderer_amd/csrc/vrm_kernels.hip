@@ -776,6 +776,77 @@ __global__ void __launch_bounds__(256) build_bricks_kernel(const uint32_t *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// evaluation reductions, HBM-streaming
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum_store(double v, double *partial)
+{
+    __shared__ double red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// compare_to_netcdf_rmse (compare/netcdf.rs:17-69): per voxel (alpha - data3)^2, and unless density_only the three
+// transfer-function colours of alpha against data0..2; every term in f32 exactly as the reference forms it, the
+// sum in f64 per block (the reference's single sequential f32 sum is neither parallel nor accurate at 10^8 terms).
+__global__ void __launch_bounds__(256) compare_volume_kernel(const uint32_t *__restrict__ vox, const float *__restrict__ data,
+                                                             size_t n, int density_only, const float ca0, const float ca1,
+                                                             const float ca2, const float cb0, const float cb1, const float cb2,
+                                                             const float cc0, const float cc1, const float cc2,
+                                                             double *__restrict__ partial)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float alpha = (float)(vox[i] >> 24) / 255.0f;                  // netcdf.rs:31
+        const float d3 = alpha - data[3 * n + i];
+        float t = d3 * d3;                                                   // netcdf.rs:32
+        acc += (double)t;
+        if (!density_only) {
+            const bool lo = alpha < 0.5f;                                    // netcdf.rs:41-57
+            const float s0 = lo ? ca0 : cb0, s1 = lo ? ca1 : cb1, s2 = lo ? ca2 : cb2;
+            const float e0 = lo ? cb0 : cc0, e1 = lo ? cb1 : cc1, e2 = lo ? cb2 : cc2;
+            // remap(value, min1, max1, 0, 1) = 0 + (value - min1) * (1 - 0) / (max1 - min1)   (netcdf.rs:81-83)
+            const float a = lo ? 0.0f + (alpha - 0.0f) * (1.0f - 0.0f) / (0.5f - 0.0f) : 0.0f + (alpha - 0.5f) * (1.0f - 0.0f) / (1.0f - 0.5f);
+            const float r = s0 * (1.0f - a) + e0 * a, gcol = s1 * (1.0f - a) + e1 * a, b = s2 * (1.0f - a) + e2 * a; // mix, :77-79
+            const float dr = r - data[i], dg = gcol - data[n + i], db = b - data[2 * n + i];
+            acc += (double)(dr * dr);
+            acc += (double)(dg * dg);
+            acc += (double)(db * db);
+        }
+    }
+    block_sum_store(acc, partial);
+}
+
+// skimage.metrics.mean_squared_error on uint8 images (similarity.py:59-61): the exact integer sum of squared
+// differences; rows of row_bytes (a multiple of 4) bytes, pitches in bytes (multiples of 4).
+__global__ void __launch_bounds__(256) ssd_u8_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, size_t row_words,
+                                                     size_t rows, size_t pitch_a, size_t pitch_b,
+                                                     unsigned long long *__restrict__ partial)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = row_words * rows;
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t row = i / row_words, col = i - row * row_words;
+        const uint32_t wa = *reinterpret_cast<const uint32_t *>(a + row * pitch_a + 4 * col);
+        const uint32_t wb = *reinterpret_cast<const uint32_t *>(b + row * pitch_b + 4 * col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = (int)((wa >> (8 * k)) & 0xffu) - (int)((wb >> (8 * k)) & 0xffu);
+            acc += (unsigned long long)(d * d);
+        }
+    }
+    __shared__ unsigned long long red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(uint32_t *dst, size_t n, uint32_t value)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -896,5 +967,22 @@ hipError_t vrm_launch_fill(uint32_t *dst, size_t n, uint32_t value, hipStream_t 
 hipError_t vrm_launch_detect_nonscalar(const uint32_t *vox, size_t n, uint32_t *flag_dev, hipStream_t stream)
 {
     hipLaunchKernelGGL(detect_nonscalar_kernel, dim3(stream_blocks(n)), dim3(256), 0, stream, vox, n, flag_dev);
+    return hipGetLastError();
+}
+
+uint32_t vrm_reduce_blocks(size_t n_items) { return stream_blocks(n_items); }
+
+hipError_t vrm_launch_compare_volume(const uint32_t *vox, const float *data_czyx, size_t n, bool density_only, const float tf9[9],
+                                     double *partial, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(compare_volume_kernel, dim3(blocks), dim3(256), 0, stream, vox, data_czyx, n, density_only ? 1 : 0, tf9[0],
+                       tf9[1], tf9[2], tf9[3], tf9[4], tf9[5], tf9[6], tf9[7], tf9[8], partial);
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_words, size_t rows, size_t pitch_a, size_t pitch_b,
+                             unsigned long long *partial, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssd_u8_kernel, dim3(blocks), dim3(256), 0, stream, a, b, row_words, rows, pitch_a, pitch_b, partial);
     return hipGetLastError();
 }
