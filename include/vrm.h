@@ -165,6 +165,35 @@ VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, floa
 /* loaders/dat.rs:10-82: parse `ObjectFileName/Resolution/Format`, read the RAW next to it, upload. */
 VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
 
+/* ---- sort-last rendering of a z-slab-partitioned volume (no reference counterpart: ---------
+ * ---- the reference holds the whole volume in one 3D texture, texture_3d.rs:22-80, state.rs:59) ---------- */
+
+/* VoxelGrid::new for ONE SLAB of an x*y*z volume: this context will own the samples whose position lies in the
+ * slices [z_begin, z_end) and stores slices [max(z_begin-1,0), min(z_end+1,z)) -- one ghost slice either side, what
+ * the trilinear filter of an owned sample can touch.  Box, step lattice, t_min/t_max stay those of the WHOLE volume
+ * (vrm_get_grid_uniform reports x,y,z), so every rank marches the same global sample lattice and each sample has
+ * exactly one owner (half-open world-space bounds, the same f32 expression on every rank).  The upload calls then
+ * take the STORED slices only (x*y*(stored) voxels, slice order ascending).  Resets attenuation/TF like
+ * vrm_grid_resize. */
+VRM_API int vrm_grid_resize_slab(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t z_begin, uint32_t z_end);
+/* stored slice range and owned slice range of the current grid ([0,z) twice for an unpartitioned grid) */
+VRM_API int vrm_grid_get_slab(vrm_ctx *ctx, uint32_t *z_store_begin, uint32_t *z_store_end, uint32_t *z_begin, uint32_t *z_end);
+
+/* RayMarcher::draw of n views into caller-owned DEVICE memory as premultiplied f32 RGBA (n * height * width * 4
+ * floats, rows top to bottom, no padding): the accumulators of wgsl:193 before the Rgba8Unorm store.  For a slab
+ * context this is the slab's partial image.  Enqueue only, on the context's stream: vrm_synchronize before another
+ * stream or library (RCCL) reads it. */
+VRM_API int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, uint32_t width, uint32_t height,
+                             float *rgba_f32_device);
+
+/* "Over"-composite n_slabs partial images of the rows [row0, row0+rows) of one view -- partials_device[slab][row]
+ * [x][4] floats, slab 0 lowest in z -- in the order the pixel's ray visits the slabs (ascending iff rd.z >= 0) and
+ * store the rows like the single-GPU path does: RGBA8 (rows*width*4 bytes, round(clamp(v,0,1)*255)) and/or f32
+ * (either output may be NULL).  Enqueue only. */
+VRM_API int vrm_composite(vrm_ctx *ctx, const vrm_camera_uniform *camera, const float *partials_device, uint32_t n_slabs,
+                          uint32_t width, uint32_t height, uint32_t row0, uint32_t rows, uint8_t *out_rgba8_device,
+                          float *out_f32_device);
+
 /* ---- evaluation (the DiffDVR loop around the path) ---------------------------- */
 
 /* compare_to_netcdf_rmse (compare/netcdf.rs:8-75): RMSE between the loaded grid and a `color(c,z,y,x)` f32

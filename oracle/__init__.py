@@ -59,6 +59,9 @@ def lib():
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_geometry.argtypes = [f32p, u32p, ctypes.c_uint32, ctypes.c_uint32, f32p]
         L.orc_geometry.restype = None
+        L.orc_render_slab.argtypes = [u8p, u32p, f32p, u32p, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.c_uint32, f32p, ctypes.c_int]
+        L.orc_render_slab.restype = ctypes.c_uint64
         L.orc_compare_volume.argtypes = [u8p, f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, f32p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double)]
         L.orc_compare_volume.restype = ctypes.c_float
@@ -192,3 +195,17 @@ def compare_volume(voxels_zyxc, data_czyx, tf_colors=DEFAULT_TF_COLORS, density_
     r = lib().orc_compare_volume(_p(v, ctypes.c_uint8), _p(d, ctypes.c_float), X, Y, Z, _p(tf9, ctypes.c_float),
                                  1 if density_only else 0, ctypes.byref(f64))
     return float(r), float(f64.value)
+
+
+def render_slab(voxels_zyxc, cam36, width, height, z_begin, z_end, attenuation=1.0, tf=None, threads=None):
+    """Partial premultiplied f32 RGBA image (H, W, 4) of the z slab [z_begin, z_end) of a sort-last render."""
+    v = np.ascontiguousarray(voxels_zyxc, dtype=np.uint8)
+    Z, Y, X, _ = v.shape
+    dims = np.array([X, Y, Z], dtype=np.uint32)
+    cam = np.ascontiguousarray(cam36, dtype=np.float32)
+    tfw = tf_words(False) if tf is None else np.ascontiguousarray(tf, dtype=np.uint32)
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    nt = threads if threads is not None else max(1, min(16, os.cpu_count() or 1))
+    lib().orc_render_slab(_p(v, ctypes.c_uint8), _p(dims, ctypes.c_uint32), _p(cam, ctypes.c_float), _p(tfw, ctypes.c_uint32),
+                          ctypes.c_float(attenuation), width, height, int(z_begin), int(z_end), _p(out, ctypes.c_float), nt)
+    return out

@@ -312,6 +312,10 @@ typedef struct {
     float col_a[3], col_b[3], col_c[3];
     int use_tf;
     const float *cam;      /* 36 floats */
+    /* sort-last partial renders (no reference counterpart): with slab != 0 only samples whose position
+     * has z in [slab_lo, slab_hi) contribute; every other sample reads as scene() == 0, i.e. adds exactly nothing */
+    int slab;
+    float slab_lo, slab_hi;
 } scene_t;
 
 #define MAX_STEP_AMOUNT 5000 /* wgsl:96 */
@@ -361,6 +365,7 @@ static void scene(const scene_t *s, const float p[3], float out[4])
     }
     if (p[0] < s->box_min[0] || p[1] < s->box_min[1] || p[2] < s->box_min[2]) return;
     if (p[0] >= box_max[0] || p[1] >= box_max[1] || p[2] >= box_max[2]) return;
+    if (s->slab && (p[2] < s->slab_lo || p[2] >= s->slab_hi)) return;
     texture_sample(s, rel, out);
 }
 
@@ -469,11 +474,12 @@ static uint32_t shade_pixel(const scene_t *s, uint32_t px, uint32_t py, uint32_t
  * out_f32 (W*H*4), out_rgba8 (W*H*4), out_steps (W*H) are each optional (NULL to skip).
  * Returns the total number of loop iterations over all rays (the reference-equivalent sample count).
  */
-ORC_API uint64_t orc_render(const uint8_t *voxels, const uint32_t dims[3], const float cam36[36], const uint32_t tf16[16],
+static uint64_t render_impl(const uint8_t *voxels, const uint32_t dims[3], const float cam36[36], const uint32_t tf16[16],
                             float attenuation, uint32_t W, uint32_t H, float *out_f32, uint8_t *out_rgba8,
-                            uint32_t *out_steps, int n_threads)
+                            uint32_t *out_steps, int n_threads, int slab, uint32_t z_begin, uint32_t z_end)
 {
     scene_t s;
+    memset(&s, 0, sizeof s);
     uint32_t d4[4];
     float bmin[4], bsz[4], buf[4];
     orc_grid_uniform(dims, attenuation, d4, bmin, bsz, buf);
@@ -484,6 +490,13 @@ ORC_API uint64_t orc_render(const uint8_t *voxels, const uint32_t dims[3], const
     for (int i = 0; i < 3; ++i) { s.col_a[i] = tf[i]; s.col_b[i] = tf[4 + i]; s.col_c[i] = tf[8 + i]; }
     s.use_tf = tf16[12] != 0;
     s.cam = cam36;
+    if (slab) {
+        /* world-space bounds of the slices [z_begin, z_end): the box faces at the ends, one shared f32 value between */
+        const float Zf = (float)dims[2];
+        s.slab = 1;
+        s.slab_lo = z_begin == 0 ? s.box_min[2] : s.box_min[2] + ((float)z_begin / Zf) * s.box_size[2];
+        s.slab_hi = z_end == dims[2] ? s.box_min[2] + s.box_size[2] : s.box_min[2] + ((float)z_end / Zf) * s.box_size[2];
+    }
 
     uint64_t total = 0;
     if (n_threads < 1) n_threads = 1;
@@ -500,6 +513,23 @@ ORC_API uint64_t orc_render(const uint8_t *voxels, const uint32_t dims[3], const
         }
     }
     return total;
+}
+
+ORC_API uint64_t orc_render(const uint8_t *voxels, const uint32_t dims[3], const float cam36[36], const uint32_t tf16[16],
+                            float attenuation, uint32_t W, uint32_t H, float *out_f32, uint8_t *out_rgba8,
+                            uint32_t *out_steps, int n_threads)
+{
+    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, out_rgba8, out_steps, n_threads, 0, 0, 0);
+}
+
+/* The partial image of the z slab [z_begin, z_end) of a sort-last render: the whole volume's sample lattice, only the
+ * slab's samples blended.  Compositing the partials of a partition with "over" in ray order gives orc_render's image
+ * up to f32 re-association. */
+ORC_API uint64_t orc_render_slab(const uint8_t *voxels, const uint32_t dims[3], const float cam36[36], const uint32_t tf16[16],
+                                 float attenuation, uint32_t W, uint32_t H, uint32_t z_begin, uint32_t z_end, float *out_f32,
+                                 int n_threads)
+{
+    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, NULL, NULL, n_threads, 1, z_begin, z_end);
 }
 
 /* Point sample for unit tests: scene(p) with the given grid (wgsl:199-238) */

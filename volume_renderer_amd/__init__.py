@@ -124,6 +124,23 @@ class VoxelGrid:
         self.attenuation = 1.0
         self.transfer_function_colors = self._default_tf()
 
+    def new_slab(self, dimensions, z_begin, z_end):
+        """One z slab of a `dimensions` volume for sort-last rendering (vrm_grid_resize_slab): owns the slices
+        [z_begin, z_end), stores one ghost slice either side.  Afterwards `dimensions` is the STORED shape the upload
+        calls expect; returns (z_store_begin, z_store_end)."""
+        x, y, z = (int(d) for d in dimensions)
+        _ffi.check(_ffi.lib().vrm_grid_resize_slab(self._rm._h, x, y, z, int(z_begin), int(z_end)))
+        s0, s1 = self.stored_slices()
+        self.dimensions = (x, y, s1 - s0)
+        self.attenuation = 1.0
+        self.transfer_function_colors = self._default_tf()
+        return s0, s1
+
+    def stored_slices(self):
+        s0, s1 = ctypes.c_uint32(), ctypes.c_uint32()
+        _ffi.check(_ffi.lib().vrm_grid_get_slab(self._rm._h, ctypes.byref(s0), ctypes.byref(s1), None, None))
+        return s0.value, s1.value
+
     def upload_rgba8(self, voxels_zyxc):
         """set_color over the grid + update_buffer (grid.rs:202-238). voxels: uint8 (Z,Y,X,4)."""
         v = np.ascontiguousarray(voxels_zyxc, dtype=np.uint8)
@@ -152,7 +169,9 @@ class VoxelGrid:
         _ffi.check(_ffi.lib().vrm_grid_upload_scalar(self._rm._h, r.ctypes.data, r.nbytes, bytes_per_sample))
 
     def download_rgba8(self):
-        x, y, z = (int(d) for d in self.uniform().dimensions[:3])
+        x, y, _ = (int(d) for d in self.uniform().dimensions[:3])
+        s0, s1 = self.stored_slices()
+        z = s1 - s0                                   # the stored slices (all of them unless slab-partitioned)
         self.dimensions = (x, y, z)
         out = np.zeros((z, y, x, 4), dtype=np.uint8)
         _ffi.check(_ffi.lib().vrm_grid_download_rgba8(self._rm._h, out.ctypes.data, out.nbytes))
@@ -268,6 +287,18 @@ class RayMarcher:
         cams = (CameraUniform * n)(*camera_uniforms)
         hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
         _ffi.check(_ffi.lib().vrm_draw_batch(self._h, cams, n, hs))
+
+    def draw_partial(self, camera_uniforms, width, height, device_ptr):
+        """n views as premultiplied f32 RGBA into caller-owned device memory (n*H*W*4 floats); enqueue only.  For a slab
+        grid (VoxelGrid.new_slab) this is the slab's partial image of a sort-last render."""
+        n = len(camera_uniforms)
+        cams = (CameraUniform * n)(*camera_uniforms)
+        _ffi.check(_ffi.lib().vrm_draw_partial(self._h, cams, n, int(width), int(height), int(device_ptr)))
+
+    def composite(self, camera_uniform, partials_ptr, n_slabs, width, height, row0, rows, out_rgba8_ptr=None, out_f32_ptr=None):
+        """Over-composite n_slabs partials ([slab][row][x][4] f32, device) of rows [row0, row0+rows) of one view; enqueue only."""
+        _ffi.check(_ffi.lib().vrm_composite(self._h, ctypes.byref(camera_uniform), int(partials_ptr), int(n_slabs), int(width),
+                                            int(height), int(row0), int(rows), out_rgba8_ptr, out_f32_ptr))
 
     def count_reference_samples(self, camera_uniforms, width, height):
         """loop iterations the reference would execute for these views (unit of Gsamples/s)."""

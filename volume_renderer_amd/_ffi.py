@@ -86,6 +86,11 @@ SYMBOLS = {
     "vrm_image_read_ray_diagnostics": (ctypes.c_int, [_vp, _f32p]),
     "vrm_count_reference_samples": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
+    "vrm_grid_resize_slab": (ctypes.c_int, [_vp] + [ctypes.c_uint32] * 5),
+    "vrm_grid_get_slab": (ctypes.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
+    "vrm_draw_partial": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "vrm_composite": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.c_uint32, ctypes.c_uint32, _vp, _vp]),
     "vrm_compare_volume_f32": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _f32p]),
     "vrm_compare_volume_f32_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _f32p]),
     "vrm_image_ssd": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

@@ -77,6 +77,22 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
+    ctx->gdim[0] = x; ctx->gdim[1] = y; ctx->gdim[2] = z;
+    ctx->z_store0 = 0;
+    ctx->slab_z0 = 0;
+    ctx->slab_z1 = z;
+    return VRM_OK;
+}
+
+static int grid_reset_contents(vrm_ctx *ctx)
+{
+    // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
+    HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
+    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
+    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
+    ctx->scalar = false;
+    ctx->attenuation = 1.0f;   // grid.rs:100,197
+    tf_defaults(&ctx->tf);     // grid.rs:198
     return VRM_OK;
 }
 
@@ -86,13 +102,33 @@ extern "C" int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     if (rc) return rc;
     rc = grid_alloc(ctx, x, y, z);
     if (rc) return rc;
-    // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
-    HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
-    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
-    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
-    ctx->scalar = false;
-    ctx->attenuation = 1.0f;   // grid.rs:100,197
-    tf_defaults(&ctx->tf);     // grid.rs:198
+    return grid_reset_contents(ctx);
+}
+
+extern "C" int vrm_grid_resize_slab(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t z_begin, uint32_t z_end)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(x > 0 && y > 0 && z > 0, "grid dimensions must be non-zero (got %u x %u x %u)", x, y, z);
+    REQUIRE(z_begin < z_end && z_end <= z, "slab [%u, %u) is not a non-empty range inside [0, %u)", z_begin, z_end, z);
+    // one ghost slice either side: a sample of slice range [z_begin, z_end) filters texels z_begin-1 .. z_end
+    const uint32_t s0 = z_begin > 0 ? z_begin - 1 : 0, s1 = z_end < z ? z_end + 1 : z;
+    rc = grid_alloc(ctx, x, y, s1 - s0);
+    if (rc) return rc;
+    ctx->gdim[2] = z;
+    ctx->z_store0 = s0;
+    ctx->slab_z0 = z_begin;
+    ctx->slab_z1 = z_end;
+    return grid_reset_contents(ctx);
+}
+
+extern "C" int vrm_grid_get_slab(vrm_ctx *ctx, uint32_t *z_store_begin, uint32_t *z_store_end, uint32_t *z_begin, uint32_t *z_end)
+{
+    REQUIRE(ctx != nullptr, "null context");
+    if (z_store_begin) *z_store_begin = ctx->z_store0;
+    if (z_store_end) *z_store_end = ctx->z_store0 + ctx->dim[2];
+    if (z_begin) *z_begin = ctx->slab_z0;
+    if (z_end) *z_end = ctx->slab_z1;
     return VRM_OK;
 }
 
@@ -266,14 +302,15 @@ extern "C" int vrm_set_transfer_function(vrm_ctx *ctx, const vrm_transfer_functi
 // VoxelGridUniform::new (grid.rs:265-280), f32 arithmetic as written there
 static void grid_uniform(const vrm_ctx *ctx, vrm_grid_uniform *u)
 {
-    uint32_t mn = ctx->dim[0] < ctx->dim[1] ? ctx->dim[0] : ctx->dim[1];
-    if (ctx->dim[2] < mn) mn = ctx->dim[2];
+    // (of the whole volume: a slab-partitioned context marches the same box as every other rank)
+    uint32_t mn = ctx->gdim[0] < ctx->gdim[1] ? ctx->gdim[0] : ctx->gdim[1];
+    if (ctx->gdim[2] < mn) mn = ctx->gdim[2];
     for (int i = 0; i < 3; ++i) {
-        u->dimensions[i] = ctx->dim[i];
-        u->box_size[i] = (float)ctx->dim[i] / (float)mn;
+        u->dimensions[i] = ctx->gdim[i];
+        u->box_size[i] = (float)ctx->gdim[i] / (float)mn;
         u->box_min[i] = -u->box_size[i] / 2.0f;
     }
-    u->dimensions[3] = ctx->dim[0];
+    u->dimensions[3] = ctx->gdim[0];
     u->box_size[3] = 0.0f;
     u->box_min[3] = 0.0f;
     for (int i = 0; i < 4; ++i) u->buffer[i] = ctx->attenuation;
@@ -451,9 +488,19 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
         g.box_min[i] = u.box_min[i];
         g.box_size[i] = u.box_size[i];
         g.box_max[i] = u.box_min[i] + u.box_size[i]; // wgsl:202,250
-        g.tex_scale[i] = (float)ctx->dim[i] / u.box_size[i];
+        g.tex_scale[i] = (float)ctx->gdim[i] / u.box_size[i];
         g.tex_bias[i] = -u.box_min[i] * g.tex_scale[i] - 0.5f;
+        g.u_lo[i] = -0.5f;
+        g.u_hi[i] = (float)ctx->dim[i] - 0.5f;
     }
+    // slab partition: texel z relative to the first stored slice; membership bounds in world space, the same
+    // expression on every rank so that neighbouring slabs share one boundary value and each sample has one owner
+    const float Zf = (float)ctx->gdim[2];
+    g.tex_bias[2] -= (float)ctx->z_store0;
+    g.u_lo[2] = (float)ctx->slab_z0 - 0.5f - (float)ctx->z_store0;
+    g.u_hi[2] = (float)ctx->slab_z1 - 0.5f - (float)ctx->z_store0;
+    g.in_min_z = ctx->slab_z0 == 0 ? g.box_min[2] : u.box_min[2] + ((float)ctx->slab_z0 / Zf) * u.box_size[2];
+    g.in_max_z = ctx->slab_z1 == ctx->gdim[2] ? g.box_max[2] : u.box_min[2] + ((float)ctx->slab_z1 / Zf) * u.box_size[2];
     p->width = w;
     p->height = h;
     p->pitch_px = (uint32_t)(pitch / 4);
@@ -510,6 +557,7 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
         d.diag_rgba = diag ? targets[i]->diag_rgba : nullptr;
         d.diag_iters = diag ? targets[i]->diag_iters : nullptr;
         d.diag_geom = diag ? targets[i]->diag_geom : nullptr;
+        d.partial_rgba = nullptr;
     }
     HIP_TRY(hipMemcpyAsync(ctx->views_dev + slot, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
 
@@ -546,6 +594,56 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
 extern "C" int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *target)
 {
     return vrm_draw_batch(ctx, camera, 1, &target);
+}
+
+// ---- sort-last ----------------------------------------------------------------------
+
+extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, uint32_t width, uint32_t height,
+                                float *rgba_f32_device)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(cameras != nullptr && rgba_f32_device != nullptr, "null argument");
+    REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
+    REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
+    if (ctx->views_cap + n > kViewRing) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->views_cap = 0;
+    }
+    const uint32_t slot = ctx->views_cap;
+    ctx->views_cap += n;
+    for (uint32_t i = 0; i < n; ++i) {
+        VrmViewDesc &d = ctx->views_host[slot + i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.ivp, cameras[i].inverse_view_proj, 64);
+        memcpy(d.pos, cameras[i].position, 16);
+        d.partial_rgba = rgba_f32_device + (size_t)i * width * height * 4;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->views_dev + slot, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    VrmMarchParams p;
+    memset(&p, 0, sizeof p);
+    fill_params(ctx, &p, width, height, (size_t)width * 4);
+    p.views = ctx->views_dev + slot;
+    HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, false, ctx->opt_skip != 0, ctx->stream));
+    return VRM_OK;
+}
+
+extern "C" int vrm_composite(vrm_ctx *ctx, const vrm_camera_uniform *camera, const float *partials_device, uint32_t n_slabs,
+                             uint32_t width, uint32_t height, uint32_t row0, uint32_t rows, uint8_t *out_rgba8_device,
+                             float *out_f32_device)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(camera != nullptr && partials_device != nullptr, "null argument");
+    REQUIRE(out_rgba8_device != nullptr || out_f32_device != nullptr, "no output buffer");
+    REQUIRE(n_slabs > 0 && n_slabs <= 4096, "slab count %u out of range", n_slabs);
+    REQUIRE(width > 0 && height > 0 && rows > 0 && row0 < height && rows <= height - row0, "rows [%u, %u) outside the %u x %u image",
+            row0, row0 + rows, width, height);
+    VrmCompositeView cv;
+    memcpy(cv.ivp, camera->inverse_view_proj, 64);
+    HIP_TRY(vrm_launch_composite(partials_device, n_slabs, cv, width, height, row0, rows, (uint32_t *)out_rgba8_device, out_f32_device,
+                                 ctx->stream));
+    return VRM_OK;
 }
 
 extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, uint32_t width,

@@ -15,6 +15,7 @@ struct VrmViewDesc {
     float *diag_rgba;    // optional W*H*4 f32 (VRM_OPT_DIAGNOSTICS)
     uint32_t *diag_iters; // optional W*H u32
     float *diag_geom;     // optional W*H*8 f32: rd.xyz, t_min, t_max, #samples inside the box, hit, 0
+    float *partial_rgba;  // optional W*H*4 f32: the premultiplied colour and alpha before the 8-bit store (sort-last partials)
 };
 
 // Volume as the kernels see it.
@@ -34,6 +35,14 @@ struct VrmGridDev {
     float box_size[3];
     float tex_scale[3];  // dim / box_size
     float tex_bias[3];   // -box_min*tex_scale - 0.5
+    // Slab partition (sort-last).  box_*, tex_scale are always those of the WHOLE volume; `vox`,
+    // `bricks`, `occ` and dim[2] describe the slices this context stores (its slab plus one ghost slice either side),
+    // tex_bias[2] is shifted so that texel coordinates are relative to the first stored slice.  A sample belongs to
+    // this context iff it passes the in-box test with z in [in_min_z, in_max_z) -- the slab's world-space bounds,
+    // box_min[2] / box_max[2] for an unpartitioned volume.  u_lo/u_hi: the texel-coordinate range [u_lo, u_hi) such
+    // samples can have (-0.5 and dim - 0.5 unpartitioned).
+    float in_min_z, in_max_z;
+    float u_lo[3], u_hi[3];
 };
 
 struct VrmMarchParams {
@@ -66,3 +75,10 @@ hipError_t vrm_launch_compare_volume(const uint32_t *vox, const float *data_czyx
                                      const float tf9[9], double *partial, uint32_t blocks, hipStream_t stream);
 hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_words, size_t rows, size_t pitch_a, size_t pitch_b,
                              unsigned long long *partial, uint32_t blocks, hipStream_t stream);
+
+// sort-last compositing: the part of a view the compositing kernel needs (the sign of rd.z per pixel)
+struct VrmCompositeView {
+    float ivp[16];
+};
+hipError_t vrm_launch_composite(const float *partials, uint32_t n_slabs, const VrmCompositeView &cv, uint32_t width, uint32_t height,
+                                uint32_t row0, uint32_t rows, uint32_t *out_rgba8, float *out_f32, hipStream_t stream);

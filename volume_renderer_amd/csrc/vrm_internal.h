@@ -13,7 +13,11 @@ struct vrm_ctx {
     hipStream_t copy_stream = nullptr; // device->host readbacks, ordered behind draws by events
 
     // VoxelGrid (voxel/grid.rs:9-22)
-    uint32_t dim[3] = {0, 0, 0};
+    uint32_t dim[3] = {0, 0, 0};  // of the stored voxels
+    // slab partition (sort-last): the whole volume is gdim; this context stores z slices [z_store0, z_store0 + dim[2])
+    // and owns the samples of slices [slab_z0, slab_z1).  Unpartitioned: gdim == dim, z_store0 = 0, slab = [0, dim[2]).
+    uint32_t gdim[3] = {0, 0, 0};
+    uint32_t z_store0 = 0, slab_z0 = 0, slab_z1 = 0;
     uint32_t *vox = nullptr; // RGBA8 words, x fastest
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere

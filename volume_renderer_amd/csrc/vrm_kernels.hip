@@ -191,7 +191,9 @@ __device__ __forceinline__ void store_pixel(const VrmViewDesc &v, const VrmMarch
                                             const Accum &acc, const Ray &ray, uint32_t iters, uint32_t n_inside)
 {
     const uint32_t packed = unorm8(acc.cr) | (unorm8(acc.cg) << 8) | (unorm8(acc.cb) << 16) | (unorm8(acc.alpha) << 24);
-    v.out[(size_t)py * P.pitch_px + px] = packed;
+    if (v.out) v.out[(size_t)py * P.pitch_px + px] = packed;
+    if (v.partial_rgba) // wave-uniform
+        reinterpret_cast<float4 *>(v.partial_rgba)[(size_t)py * P.width + px] = make_float4(acc.cr, acc.cg, acc.cb, acc.alpha);
     if (DIAG) {
         const size_t o = (size_t)py * P.width + px;
         if (v.diag_rgba) reinterpret_cast<float4 *>(v.diag_rgba)[o] = make_float4(acc.cr, acc.cg, acc.cb, acc.alpha);
@@ -249,8 +251,8 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
             const float p0 = ray.ro[0] + ray.rd[0] * dt;
             const float p1 = ray.ro[1] + ray.rd[1] * dt;
             const float p2 = ray.ro[2] + ray.rd[2] * dt;
-            const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
-                                (p1 < g.box_max[1]) & (p2 < g.box_max[2]); // wgsl:218-223
+            const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
+                                (p1 < g.box_max[1]) & (p2 < g.in_max_z); // wgsl:218-223
             if (inside) {
                 if (DIAG) ++n_inside;
                 const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
@@ -416,8 +418,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
                 blo[a] = wave_min(n_lane > 0 ? fminf(ua[a], ue) : __builtin_inff()) - 0.01f;
                 bhi[a] = wave_max(n_lane > 0 ? fmaxf(ua[a], ue) : -__builtin_inff()) + 0.01f;
-                ilo[a] = uni((int)floorf(fmaxf(blo[a], -1.0f)));
-                ihi[a] = uni((int)floorf(fminf(bhi[a], (float)g.dim[a] - 0.5f)) + 1);
+                // (z of a slab-partitioned volume: samples outside the slab's own range fail the test too, so a chunk
+                // that lies in another rank's slab degenerates to `none` and only advances dt)
+                ilo[a] = uni((int)floorf(fmaxf(blo[a], g.u_lo[a] - 0.5f)));
+                ihi[a] = uni((int)floorf(fminf(bhi[a], g.u_hi[a])) + 1);
             }
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-texel boundary: the staging loads are whole 16-byte quads of the bricked volume
@@ -528,8 +532,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     if (DIAG) {
                         ++iters;
                         const float p0 = ray.ro[0] + ray.rd[0] * dt, p1 = ray.ro[1] + ray.rd[1] * dt, p2 = ray.ro[2] + ray.rd[2] * dt;
-                        n_inside += ((p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
-                                     (p1 < g.box_max[1]) & (p2 < g.box_max[2])) ? 1u : 0u;
+                        n_inside += ((p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
+                                     (p1 < g.box_max[1]) & (p2 < g.in_max_z)) ? 1u : 0u;
                     }
                     dt += VRM_STEP_SIZE;
                     active = !(dt >= ray.t_max);
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float eps = 0.03f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-                interior = interior && (blo[a] - eps >= -0.5f) && (bhi[a] + eps <= (float)g.dim[a] - 0.5f);
+                interior = interior && (blo[a] - eps >= g.u_lo[a]) && (bhi[a] + eps <= g.u_hi[a]);
             }
             interior = uni(interior ? 1 : 0) != 0;
             const float fpx = (float)pitch, fsl = (float)slice;
@@ -575,8 +579,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             const float p0 = ray.ro[0] + ray.rd[0] * dt;
                             const float p1 = ray.ro[1] + ray.rd[1] * dt;
                             const float p2 = ray.ro[2] + ray.rd[2] * dt;
-                            inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
-                                     (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
+                            inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
+                                     (p1 < g.box_max[1]) & (p2 < g.in_max_z);
                             u0 = __builtin_fmaf(p0, g.tex_scale[0], bl[0]);
                             u1 = __builtin_fmaf(p1, g.tex_scale[1], bl[1]);
                             u2 = __builtin_fmaf(p2, g.tex_scale[2], bl[2]);
@@ -615,8 +619,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     const float p0 = ray.ro[0] + ray.rd[0] * dt;
                     const float p1 = ray.ro[1] + ray.rd[1] * dt;
                     const float p2 = ray.ro[2] + ray.rd[2] * dt;
-                    const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.box_min[2]) & (p0 < g.box_max[0]) &
-                                        (p1 < g.box_max[1]) & (p2 < g.box_max[2]);
+                    const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
+                                        (p1 < g.box_max[1]) & (p2 < g.in_max_z);
                     bool done = false;
                     if (inside) {
                         if (DIAG) ++n_inside;
@@ -773,6 +777,39 @@ __global__ void __launch_bounds__(256) build_bricks_kernel(const uint32_t *__res
         w.z = row[min(x + 2u, X - 1u)];
         w.w = row[min(x + 3u, X - 1u)];
         bricks[i] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sort-last compositing: `n_slabs` premultiplied f32 RGBA partials of the same image rows, slab 0
+// lowest in z, are blended with the associative "over" operator in the order the ray visits the slabs -- ascending
+// when rd.z >= 0, descending otherwise (rd.z as fs_main forms it, wgsl:98-108; its sign is that of the
+// un-normalised z) -- and stored like the single-GPU path stores its pixel.  HBM-streaming.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) composite_kernel(const float4 *__restrict__ partials, uint32_t n_slabs, VrmCompositeView cv,
+                                                        uint32_t width, uint32_t height, uint32_t row0, uint32_t rows,
+                                                        uint32_t *__restrict__ out_rgba8, float4 *__restrict__ out_f32)
+{
+    const size_t n = (size_t)rows * width, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t yb = (uint32_t)(i / width), px = (uint32_t)(i - (size_t)yb * width), py = row0 + yb;
+        const float uvx = ((float)px + 0.5f) / (float)width;
+        const float uvy = 1.0f - ((float)py + 0.5f) / (float)height;
+        const float sx = uvx * 2.0f - 1.0f, sy = uvy * 2.0f - 1.0f;
+        const float wz = ((cv.ivp[2] * sx + cv.ivp[6] * sy) + cv.ivp[10] * 1.0f) + cv.ivp[14] * 1.0f;
+        const bool ascending = wz >= 0.0f;
+        Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t s = 0; s < n_slabs; ++s) {
+            const uint32_t k = ascending ? s : n_slabs - 1u - s;
+            const float4 p = partials[(size_t)k * n + i];
+            const float om = 1.0f - acc.alpha;
+            acc.cr = __builtin_fmaf(om, p.x, acc.cr);
+            acc.cg = __builtin_fmaf(om, p.y, acc.cg);
+            acc.cb = __builtin_fmaf(om, p.z, acc.cb);
+            acc.alpha = __builtin_fmaf(om, p.w, acc.alpha);
+        }
+        if (out_rgba8) out_rgba8[i] = unorm8(acc.cr) | (unorm8(acc.cg) << 8) | (unorm8(acc.cb) << 16) | (unorm8(acc.alpha) << 24);
+        if (out_f32) out_f32[i] = make_float4(acc.cr, acc.cg, acc.cb, acc.alpha);
     }
 }
 
@@ -984,5 +1021,14 @@ hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_word
                              unsigned long long *partial, uint32_t blocks, hipStream_t stream)
 {
     hipLaunchKernelGGL(ssd_u8_kernel, dim3(blocks), dim3(256), 0, stream, a, b, row_words, rows, pitch_a, pitch_b, partial);
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_composite(const float *partials, uint32_t n_slabs, const VrmCompositeView &cv, uint32_t width, uint32_t height,
+                                uint32_t row0, uint32_t rows, uint32_t *out_rgba8, float *out_f32, hipStream_t stream)
+{
+    hipLaunchKernelGGL(composite_kernel, dim3(stream_blocks((size_t)rows * width)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(partials), n_slabs, cv, width, height, row0, rows, out_rgba8,
+                       reinterpret_cast<float4 *>(out_f32));
     return hipGetLastError();
 }
