@@ -22,6 +22,103 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def run_c5(a):
+    """C5: sort-last render of a dim x dim x 2*dim scalar volume cut into one z slab per rank.  Every rank
+    generates and ingests ONLY its slab (+ ghost slices), marches the whole volume's sample lattice restricted to its
+    slab into f32 partials, one RCCL all-to-all moves row bands, every rank composites its band.  One step = all views.
+    The volume never exists on one GPU, so "scaling" is strong in the sense that the per-rank share shrinks with N."""
+    import numpy as np
+    import torch
+
+    import volume_renderer_amd as vr
+    from volume_renderer_amd import distributed as vd
+    from volume_renderer_amd import sortlast, synth
+
+    rank, local_rank, world = vd.env_rank()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-marching path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        vd.init_process_group("nccl")
+    D, R = a.c5_dim, a.c5_res
+    dims = (D, D, 2 * D)
+    rm = vr.RayMarcher(local_rank, R, R)
+    rm.set_option(vr.OPT_KERNEL, a.kernel)
+    rm.set_option(vr.OPT_SKIP_EMPTY, a.skip_empty)
+    slr = sortlast.SortLastRenderer(rm, dims)
+    t0 = time.time()
+    slr.upload_scalar_u8(synth.blobs_scalar_u8_slices(dims, slr.s0, slr.s1))
+    rm.voxel_grid.attenuation = a.attenuation
+    rm.voxel_grid.update_voxel_grid_buffer()
+    rm.synchronize()
+    ingest_s = time.time() - t0
+
+    cam = vr.Camera(1.0)
+    xdiv, ydiv = 8, max(2, a.c5_views // 8 + 1)
+    csp = vr.CameraSphereController(ydiv, xdiv, (0.0, 0.0, 0.0), a.radius)
+    cams = []
+    for ix, iy in vr.sphere_views(xdiv, ydiv):
+        csp.current_index_x, csp.current_index_y = ix, iy
+        csp.update_position(cam)
+        cams.append(cam.uniform())
+    B = max(1, min(4, len(cams)))       # views per exchange: 4 * 64 MiB of f32 partials per rank at 2048^2
+
+    def step():
+        last = None
+        for c0 in range(0, len(cams), B):
+            last = slr.render(cams[c0:c0 + B], R, R, dev)
+        return last
+
+    n_ref = rm.count_reference_samples(cams, R, R)
+    for _ in range(a.warmup):
+        step()
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    vd.barrier()
+    elapsed = vd.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # where the time goes on this rank: march of the partials vs exchange + composite (one more, instrumented, step)
+    rm.set_option(vr.OPT_PROFILE, 1)
+    rm.profile_read()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    part = torch.empty((B, R, R, 4), dtype=torch.float32, device=dev)
+    rm.draw_partial(cams[:B], R, R, part.data_ptr())
+    rm.synchronize()
+    march_ms = (time.perf_counter() - t1) * 1e3
+    stored = slr.s1 - slr.s0
+    b_alg_view = dims[0] * dims[1] * stored * 4 + R * R * 16      # this rank: its slab read once, its f32 partial written once
+    achieved = b_alg_view * B / (march_ms * 1e-3) / 1e9
+    out = {
+        "metric": "views/s", "value": round(len(cams) * a.steps / elapsed, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C5: {dims[0]}x{dims[1]}x{dims[2]} scalar volume (blobs seed {synth.DEFAULT_SEED}) in {world} z slab(s) "
+                               f"with ghost slices, sort-last: f32 partials, direct-send all-to-all of row bands, over-composite; "
+                               f"{len(cams)} views at {R}x{R}, radius {a.radius}, attenuation {a.attenuation}",
+                   "volume": list(dims), "image": [R, R], "views": len(cams), "parallelism": f"z-slab sort-last x{world}",
+                   "kernel_variant": a.kernel, "skip_empty": a.skip_empty},
+        "gsamples_per_s": round(n_ref * a.steps / elapsed / 1e9, 3), "ms_per_view": round(elapsed / a.steps / len(cams) * 1e3, 4),
+        "slab_ingest_s": round(ingest_s, 2),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "march kernel (variant %d), rank 0's slab" % a.kernel,
+                     "avg_launch_ms": round(march_ms, 3), "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B},
+        "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    rm.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,14 +138,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the export rendered by the CPU baseline (at most)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU baseline after this much CPU-side wall time")
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "custom"],
-                    help="BASELINE.json configs[1..3]; C3 is the headline and the default; 'custom' takes --dim/--res/... as given")
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "custom"],
+                    help="BASELINE.json configs[1..3]; C3 is the headline and the default; 'custom' takes --dim/--res/... as given; "
+                         "C5 = sort-last over a z-slab-partitioned volume (SURVEY 8e), see run_c5()")
+    ap.add_argument("--c5-dim", type=int, default=1024, help="C5: volume is dim x dim x 2*dim scalar (SURVEY's 2048 needs 8 GPUs)")
+    ap.add_argument("--c5-views", type=int, default=16)
+    ap.add_argument("--c5-res", type=int, default=2048)
     ap.add_argument("--volume", default=None, choices=["rgba", "scalar"],
                     help="rgba: f32 color(c,z,y,x) NetCDF-style; scalar: DAT-style density replicated to r=g=b=a")
     a = ap.parse_args()
     presets = {"C2": dict(dim=256, res=512, xdiv=8, ydiv=9, volume="scalar"),     # 256^3 u8 DAT, 64 views, 512^2
                "C3": dict(dim=512, res=1024, xdiv=16, ydiv=17, volume="rgba"),    # 512^3 f32 RGBA, 256 views, 1024^2
                "C4": dict(dim=1024, res=2048, xdiv=16, ydiv=9, volume="scalar")}  # 1024^3 f32 scalar, 128 views, 2048^2
+    if a.config == "C5":
+        return run_c5(a)
     if a.config in presets:
         for k, v in presets[a.config].items():
             if k == "volume":

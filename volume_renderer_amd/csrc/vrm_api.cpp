@@ -496,6 +496,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     // slab partition: texel z relative to the first stored slice; membership bounds in world space, the same
     // expression on every rank so that neighbouring slabs share one boundary value and each sample has one owner
     const float Zf = (float)ctx->gdim[2];
+    g.slab = (ctx->slab_z0 != 0 || ctx->slab_z1 != ctx->gdim[2]) ? 1u : 0u;
     g.tex_bias[2] -= (float)ctx->z_store0;
     g.u_lo[2] = (float)ctx->slab_z0 - 0.5f - (float)ctx->z_store0;
     g.u_hi[2] = (float)ctx->slab_z1 - 0.5f - (float)ctx->z_store0;

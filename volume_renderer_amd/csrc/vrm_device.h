@@ -43,6 +43,7 @@ struct VrmGridDev {
     // samples can have (-0.5 and dim - 0.5 unpartitioned).
     float in_min_z, in_max_z;
     float u_lo[3], u_hi[3];
+    uint32_t slab;       // 1 => this context owns only part of the z range
 };
 
 struct VrmMarchParams {

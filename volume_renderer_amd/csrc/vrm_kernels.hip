@@ -401,6 +401,31 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         float ua[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+        if (!DIAG && g.slab) {
+            // Slab-partitioned volume: this rank marches the whole volume's lattice but blends only its slab's samples.
+            // (The diagnostics build walks every step so that its per-ray counts stay those of the unpartitioned march.)
+            const float uz = ua[2], dz = du[2], lo1 = g.u_lo[2] - 1.0f, hi1 = g.u_hi[2] + 1.0f; // one texel of margin
+            // past the slab and moving away: nothing left to blend, the accumulators are final
+            if (dz > 0.0f ? uz >= hi1 : (dz < 0.0f && uz < lo1)) active = false;
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            // before the slab: advance the running dt sum up to the slab's entry plane without a chunk prologue per K
+            // steps (du carries 1 % slack, so the step count errs on the short side)
+            float ff = 0.0f;
+            if (dz > 0.0f && uz < lo1) ff = (lo1 - uz) / dz;
+            else if (dz < 0.0f && uz >= hi1) ff = (hi1 - uz) / dz;
+            const int nff = uni((int)fminf(wave_min(active ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
+            if (nff > 0) {
+                for (int j = 0; j < nff; ++j) {
+                    if (active) {
+                        dt += VRM_STEP_SIZE;
+                        active = !(dt >= ray.t_max);
+                    }
+                }
+                steps_left -= nff;
+                active = active && steps_left > 0;
+                continue;
+            }
+        }
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
         int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane

@@ -128,6 +128,13 @@ class SortLastRenderer:
             raise ValueError(f"expected slices [{self.s0},{self.s1}) as {(self.s1 - self.s0, self.dims[1], self.dims[0], 4)}, got {v.shape}")
         self.rm.voxel_grid.upload_rgba8(v)
 
+    def upload_scalar_u8(self, stored_slices_zyx):
+        """DAT-style density of the stored slices [s0, s1): uint8 (s1-s0, Y, X), replicated to RGBA on the GPU (dat.rs:74)."""
+        v = np.ascontiguousarray(stored_slices_zyx, dtype=np.uint8)
+        if v.shape != (self.s1 - self.s0, self.dims[1], self.dims[0]):
+            raise ValueError(f"expected slices [{self.s0},{self.s1}) as {(self.s1 - self.s0, self.dims[1], self.dims[0])}, got {v.shape}")
+        self.rm.voxel_grid.upload_scalar(v.reshape(-1), (self.dims[0], self.dims[1], self.s1 - self.s0), 1)
+
     def render(self, camera_uniforms, width, height, device):
         """Render the views cooperatively.  Returns (band_rgba8, row0, rows): this rank's row band of every view as a
         torch uint8 tensor (n, rows, W, 4) on `device`."""

@@ -53,6 +53,18 @@ def blobs_density(dims, seed=DEFAULT_SEED, slab=32):
     return out
 
 
+def blobs_scalar_u8_slices(dims, z0, z1, seed=DEFAULT_SEED, slab=32):
+    """Slices [z0, z1) of blobs_scalar_u8(dims): what one rank of a slab-partitioned render stores (no whole-volume temporary)."""
+    X, Y, Z = dims
+    thr, mx = _levels(seed)
+    out = np.empty((z1 - z0, Y, X), dtype=np.uint8)
+    for a in range(z0, z1, slab):
+        b = min(z1, a + slab)
+        f = _field(dims, seed, a, b)
+        out[a - z0:b - z0] = (np.clip((f - thr) / (mx - thr), 0.0, 1.0) * 255.0).astype(np.uint8)
+    return out
+
+
 def blobs_scalar_u8(dims, seed=DEFAULT_SEED):
     """DAT-style UCHAR volume: uint8 (Z,Y,X)."""
     d = blobs_density(dims, seed)
