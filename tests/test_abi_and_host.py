@@ -105,3 +105,13 @@ def test_quantize_rgba8_helper_matches_oracle(orc):
     data = rng.uniform(-0.2, 1.3, size=(4, 5, 6, 7)).astype(np.float32)
     data[0, 0, 0, 0] = np.nan
     assert np.array_equal(synth.quantize_rgba8(data), orc.quantize_netcdf(data))
+
+
+def test_rust_sys_crate_declares_every_symbol():
+    """rust/vrm-sys (f-3) cannot be compiled here; at least it must name exactly the symbols of the ABI."""
+    import re
+    from conftest import ROOT
+    from volume_renderer_amd import _ffi
+    src = open(os.path.join(ROOT, "rust", "vrm-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (vrm_\w+)\(", src))
+    assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
