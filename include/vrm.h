@@ -165,6 +165,23 @@ VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, floa
 /* loaders/dat.rs:10-82: parse `ObjectFileName/Resolution/Format`, read the RAW next to it, upload. */
 VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
 
+/* ---- NetCDF interchange ------------------------------------------------------ */
+
+/* loaders::netcdf::open_voxel_grid (loaders/netcdf.rs:34-69): read variable `color(c,z,y,x)` (f32, c = 4), make a
+ * fresh x*y*z grid (attenuation and TF reset, netcdf.rs:47) and quantise `(v*255.0) as u8` per channel (netcdf.rs:54-57,
+ * on the GPU).  Container: netCDF classic (CDF-1, CDF-2, CDF-5).  A NetCDF-4/HDF5 file -- what the reference's
+ * netcdf crate and scripts/diffdvr.py:278 write -- is recognised and refused with VRM_ERR_IO and a message naming the
+ * conversion (`nccopy -k cdf5`); the data model is the same. */
+VRM_API int vrm_load_netcdf(vrm_ctx *ctx, const char *path);
+/* loaders::netcdf::write_voxel_grid (loaders/netcdf.rs:8-31): dimensions c=4,z,y,x and `color` = voxel/255.0 as f32,
+ * written as a classic file (CDF-1 below 2 GiB, CDF-2 below 4 GiB, CDF-5 beyond). */
+VRM_API int vrm_write_netcdf(vrm_ctx *ctx, const char *path);
+/* The container alone, host only (no context, no GPU): with color_czyx == NULL a size query that sets x, y, z;
+ * otherwise 4*x*y*z floats in file order (c slowest, x fastest) converted to host byte order. */
+VRM_API int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *color_czyx,
+                                  size_t capacity_floats);
+VRM_API int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);
+
 /* ---- sort-last rendering of a z-slab-partitioned volume (no reference counterpart: ---------
  * ---- the reference holds the whole volume in one 3D texture, texture_3d.rs:22-80, state.rs:59) ---------- */
 

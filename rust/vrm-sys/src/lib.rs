@@ -69,6 +69,11 @@ extern "C" {
     pub fn vrm_export_sphere(ctx: *mut vrm_ctx, x_div: u32, y_div: u32, radius: f32, origin: *const f32, out_dir: *const c_char,
                              part: u32, n_parts: u32) -> c_int;
     pub fn vrm_load_dat(ctx: *mut vrm_ctx, dat_path: *const c_char) -> c_int;
+    // NetCDF interchange (loaders/netcdf.rs)
+    pub fn vrm_load_netcdf(ctx: *mut vrm_ctx, path: *const c_char) -> c_int;
+    pub fn vrm_write_netcdf(ctx: *mut vrm_ctx, path: *const c_char) -> c_int;
+    pub fn vrm_netcdf_read_color(path: *const c_char, x: *mut u32, y: *mut u32, z: *mut u32, color_czyx: *mut f32, capacity_floats: usize) -> c_int;
+    pub fn vrm_netcdf_write_color(path: *const c_char, x: u32, y: u32, z: u32, color_czyx: *const f32) -> c_int;
     // sort-last rendering of a z-slab-partitioned volume
     pub fn vrm_grid_resize_slab(ctx: *mut vrm_ctx, x: u32, y: u32, z: u32, z_begin: u32, z_end: u32) -> c_int;
     pub fn vrm_grid_get_slab(ctx: *mut vrm_ctx, z_store_begin: *mut u32, z_store_end: *mut u32, z_begin: *mut u32, z_end: *mut u32) -> c_int;

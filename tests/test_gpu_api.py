@@ -236,3 +236,37 @@ def test_profiling_counts_launches(rm, vr, orc):
     assert n == 3 and ms > 0
     assert rm.profile_read() == (0.0, 0)
     img.close()
+
+
+def test_netcdf_load_and_write(rm1, vr, orc, tmp_path):
+    """open_voxel_grid / write_voxel_grid (loaders/netcdf.rs) on classic containers, against the oracle's quantisation."""
+    scipy_io = pytest.importorskip("scipy.io")
+    from volume_renderer_amd import netcdf
+    rng = np.random.default_rng(4)
+    data = rng.random((4, 7, 9, 11), dtype=np.float32) * np.float32(1.2) - np.float32(0.1)   # some values outside [0,1]: saturate
+    data[2, 3, 4, 5] = np.nan                                                                   # Rust `as u8`: NaN -> 0
+    p = os.path.join(tmp_path, "in.nc")
+    f = scipy_io.netcdf_file(p, "w", version=2)
+    for n, k in zip("czyx", data.shape):
+        f.createDimension(n, k)
+    f.createVariable("color", "f", ("c", "z", "y", "x"))[:] = data
+    f.close()
+    g = rm1.voxel_grid
+    g.attenuation = 7.0
+    g.update_voxel_grid_buffer()
+    rm1.load_netcdf(p)
+    assert g.dimensions == (11, 9, 7) and list(g.uniform().buffer) == [1.0] * 4      # VoxelGrid::new resets attenuation (netcdf.rs:47)
+    vox = g.download_rgba8()
+    assert np.array_equal(vox, orc.quantize_netcdf(data))
+    out = os.path.join(tmp_path, "out.nc")
+    rm1.write_netcdf(out)
+    back = netcdf.read_color(out)
+    want = (np.moveaxis(vox, -1, 0).astype(np.float32) / np.float32(255.0))         # voxel as f32 / 255.0 (netcdf.rs:23)
+    assert np.array_equal(back, want)
+    fr = scipy_io.netcdf_file(out, "r", mmap=False)
+    assert np.array_equal(np.asarray(fr.variables["color"].data, dtype=np.float32), want)
+    fr.close()
+    rm1.load_netcdf(out)                                                            # write -> load is the identity on the voxels
+    assert np.array_equal(g.download_rgba8(), vox)
+    with pytest.raises(vr.VrmError):
+        rm1.load_netcdf(os.path.join(tmp_path, "missing.nc"))

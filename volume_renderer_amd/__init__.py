@@ -328,6 +328,18 @@ class RayMarcher:
         self.voxel_grid.attenuation = 1.0
         self.voxel_grid.transfer_function_colors = VoxelGrid._default_tf()
 
+    def load_netcdf(self, path):
+        """loaders::netcdf::open_voxel_grid (netcdf.rs:34-69); classic NetCDF containers (see include/vrm.h)."""
+        _ffi.check(_ffi.lib().vrm_load_netcdf(self._h, os.fsencode(path)))
+        u = self.voxel_grid.uniform()
+        self.voxel_grid.dimensions = tuple(int(d) for d in u.dimensions[:3])
+        self.voxel_grid.attenuation = 1.0
+        self.voxel_grid.transfer_function_colors = VoxelGrid._default_tf()
+
+    def write_netcdf(self, path):
+        """loaders::netcdf::write_voxel_grid (netcdf.rs:8-31)."""
+        _ffi.check(_ffi.lib().vrm_write_netcdf(self._h, os.fsencode(path)))
+
     def compare_to_netcdf_rmse(self, color_czyx, density_only):
         """compare::netcdf::compare_to_netcdf_rmse (compare/netcdf.rs:8-75) against an in-memory `color(c,z,y,x)` f32 array."""
         d = _f32(color_czyx)

@@ -1,0 +1,27 @@
+"""NetCDF interchange of the path: `color(c,z,y,x)` f32 in a netCDF classic container, through
+libvrm.so (vrm_netcdf_read_color / vrm_netcdf_write_color; host code, no GPU needed).  The reference's own files are
+NetCDF-4/HDF5 (loaders/netcdf.rs:10, scripts/diffdvr.py:278); those are refused with a message naming the conversion."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _ffi
+
+
+def read_color(path):
+    """-> float32 array (4, Z, Y, X), the variable `color` as loaders/netcdf.rs:45 reads it."""
+    x, y, z = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    L = _ffi.lib()
+    _ffi.check(L.vrm_netcdf_read_color(os.fsencode(path), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z), None, 0))
+    out = np.empty((4, z.value, y.value, x.value), dtype=np.float32)
+    _ffi.check(L.vrm_netcdf_read_color(os.fsencode(path), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z), out.ctypes.data, out.size))
+    return out
+
+
+def write_color(path, color_czyx):
+    """float32 (4, Z, Y, X) -> classic NetCDF file with dimensions c, z, y, x and variable `color` (netcdf.rs:10-16)."""
+    d = np.ascontiguousarray(color_czyx, dtype=np.float32)
+    if d.ndim != 4 or d.shape[0] != 4:
+        raise ValueError(f"expected (4, Z, Y, X), got {d.shape}")
+    _ffi.check(_ffi.lib().vrm_netcdf_write_color(os.fsencode(path), d.shape[3], d.shape[2], d.shape[1], d.ctypes.data))
