@@ -218,3 +218,54 @@ def test_batch_equals_single_draws(rm, vr, orc):
         assert np.array_equal(im.read(), want)
     for im in imgs:
         im.close()
+
+
+def test_parity_step_cap_on_a_long_volume(rm, vr, orc):
+    """box_size = dims / min(dims) (grid.rs:268): a 4x4x48 volume is 12 units long, rays along z would need 12000 steps and
+    stop at the 5000th iteration (wgsl:96,139) -- per lane, wherever the chunking put that step."""
+    vox = synth.random_rgba8((4, 4, 48), 12)
+    configure(rm, vox, 0.5, False)
+    for pos, tgt in [((0.05, 0.02, 9.0), (0.0, 0.0, 0.0)), ((3.0, 0.5, 7.0), (0.0, 0.0, -2.0))]:
+        cam = orc.camera_uniform(np.array(pos, np.float32), target=tgt)
+        got = draw(rm, vr, cam, 40, 24)
+        check(orc, got, vox, cam, 40, 24, 0.5, False)
+        if pos[2] == 9.0:
+            assert got["iters"].max() == 5000
+
+
+def test_parity_wide_field_of_view_per_tile(rm, vr, orc):
+    """An 8x8 image: one wave tile spans the whole 45-degree field of view and, from inside the volume, rays of one wave
+    leave through different faces -- the lanes do not share a major axis (lockstep fallback of the plane front)."""
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((40, 40, 40)))
+    configure(rm, vox, 30.0, False)
+    for pos, tgt in [((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((0.3, -0.2, 0.1), (-1.0, 0.2, 0.4)), ((1.5, 1.4, 1.6), (0.0, 0.0, 0.0))]:
+        cam = orc.camera_uniform(np.array(pos, np.float32), target=tgt)
+        for W, H in [(8, 8), (3, 2)]:
+            got = draw(rm, vr, cam, W, H)
+            check(orc, got, vox, cam, W, H, 30.0, False)
+
+
+def test_parity_volume_dims_off_the_brick_grid(rm, vr, orc):
+    """dims that are not multiples of the 4x4x2 brick or the 4-texel staging quads, viewed so that boxes overhang every face"""
+    for dims in [(13, 11, 7), (5, 6, 9), (31, 30, 29)]:
+        vox = synth.random_rgba8(dims, sum(dims))
+        configure(rm, vox, 25.0, False)
+        for ix, iy in [(0, 4), (2, 4), (3, 1), (5, 7)]:
+            cam = sphere_cam(orc, ix, iy, radius=2.2)
+            got = draw(rm, vr, cam, 72, 56)
+            check(orc, got, vox, cam, 72, 56, 25.0, False)
+
+
+def test_production_kernel_equals_diagnostics_kernel(rm, vr, orc):
+    """The image of the kernels without the diagnostics outputs (what bench.py and every user runs) is bit-identical to
+    the diagnostics build that the parity tests above compare with the oracle."""
+    cases = [(synth.quantize_rgba8(synth.blobs_rgba_f32((48, 40, 32))), 20.0, False, [(1, 3), (6, 6), (0, 4)]),
+             (np.repeat(synth.blobs_scalar_u8((40, 40, 40))[..., None], 4, 3), 5.0, True, [(2, 2)]),
+             (synth.random_rgba8((4, 4, 48), 12), 0.5, False, [(0, 4), (2, 4)])]
+    for vox, att, tf, views in cases:
+        configure(rm, vox, att, tf)
+        for ix, iy in views:
+            cam = sphere_cam(orc, ix, iy, radius=3.0 if vox.shape[0] == 48 else 2.5)
+            a = draw(rm, vr, cam, 100, 84, diag=True)["rgba8"]
+            b = draw(rm, vr, cam, 100, 84, diag=False)["rgba8"]
+            assert np.array_equal(a, b)
