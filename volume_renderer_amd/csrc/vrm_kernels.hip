@@ -294,26 +294,49 @@ __device__ __forceinline__ float dpp_mov(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL,
                                                                  ROW_MASK, 0xF, false));
 }
+// The compiler turns update_dpp + fminf into mov, nop, mov_dpp, canonicalise, min per stage (26 VALU instructions per
+// reduction, and the chunk prologue does eight of them); written out, a stage is ONE v_min_f32_dpp whose first source is
+// the permuted copy of the register itself.  A DPP read of a VGPR needs two wait states after the VALU write of it:
+// s_nop 1 between dependent stages, or the other chain's stage plus s_nop 0 when a min and a max run interleaved.
+#define VRM_DPP_STAGES(OP)                                                          \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+    "s_nop 1"
 __device__ __forceinline__ float wave_min(float v)
 {
-    v = fminf(v, dpp_mov<0xB1, 0xF>(v));  // quad_perm [1,0,3,2]
-    v = fminf(v, dpp_mov<0x4E, 0xF>(v));  // quad_perm [2,3,0,1]
-    v = fminf(v, dpp_mov<0x141, 0xF>(v)); // row_half_mirror
-    v = fminf(v, dpp_mov<0x140, 0xF>(v)); // row_mirror
-    v = fminf(v, dpp_mov<0x142, 0xA>(v)); // row_bcast:15 into rows 1 and 3
-    v = fminf(v, dpp_mov<0x143, 0xC>(v)); // row_bcast:31 into rows 2 and 3
+    asm volatile(VRM_DPP_STAGES("v_min_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-    v = fmaxf(v, dpp_mov<0xB1, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x4E, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x141, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x140, 0xF>(v));
-    v = fmaxf(v, dpp_mov<0x142, 0xA>(v));
-    v = fmaxf(v, dpp_mov<0x143, 0xC>(v));
+    asm volatile(VRM_DPP_STAGES("v_max_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef VRM_DPP_STAGES
+// lo <- min over the wave of lo, hi <- max over the wave of hi, the two chains interleaved
+#define VRM_DPP_STAGE2(CTRL)                                          \
+    "v_min_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"              \
+    "v_max_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"              \
+    "s_nop 0\n\t"
+__device__ __forceinline__ void wave_minmax(float &lo, float &hi)
+{
+    asm volatile("s_nop 1\n\t"
+                 VRM_DPP_STAGE2("quad_perm:[1,0,3,2] row_mask:0xf")
+                 VRM_DPP_STAGE2("quad_perm:[2,3,0,1] row_mask:0xf")
+                 VRM_DPP_STAGE2("row_half_mirror row_mask:0xf")
+                 VRM_DPP_STAGE2("row_mirror row_mask:0xf")
+                 VRM_DPP_STAGE2("row_bcast:15 row_mask:0xa")
+                 VRM_DPP_STAGE2("row_bcast:31 row_mask:0xc")
+                 "s_nop 0"
+                 : "+v"(lo), "+v"(hi));
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 63));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 63));
+}
+#undef VRM_DPP_STAGE2
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -375,8 +398,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         float amax[3], amin[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            amax[a] = wave_max(active ? du[a] : -__builtin_inff());
-            amin[a] = wave_min(active ? du[a] : __builtin_inff());
+            amin[a] = active ? du[a] : __builtin_inff();
+            amax[a] = active ? du[a] : -__builtin_inff();
+            wave_minmax(amin[a], amax[a]);
         }
         float best = -1.0f;
 #pragma unroll
@@ -441,8 +465,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             for (int a = 0; a < 3; ++a) {
                 // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test
                 const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
-                blo[a] = wave_min(n_lane > 0 ? fminf(ua[a], ue) : __builtin_inff()) - 0.01f;
-                bhi[a] = wave_max(n_lane > 0 ? fmaxf(ua[a], ue) : -__builtin_inff()) + 0.01f;
+                float mn = n_lane > 0 ? fminf(ua[a], ue) : __builtin_inff(), mx = n_lane > 0 ? fmaxf(ua[a], ue) : -__builtin_inff();
+                wave_minmax(mn, mx);
+                blo[a] = mn - 0.01f;
+                bhi[a] = mx + 0.01f;
                 // (z of a slab-partitioned volume: samples outside the slab's own range fail the test too, so a chunk
                 // that lies in another rank's slab degenerates to `none` and only advances dt)
                 ilo[a] = uni((int)floorf(fmaxf(blo[a], g.u_lo[a] - 0.5f)));
