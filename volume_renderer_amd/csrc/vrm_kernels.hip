@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         for (;;) {
             // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
             const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
-            n_lane = active ? min(min((int)fminf(fmaxf(ahead, 0.0f), (float)kk), kk), steps_left) : 0;
+            n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                       ncz = (min(ihi[2], mxz) >> 2) - c0z + 1;
             const int ncxy = ncx * ncy, nc = ncxy * ncz;
             if (nc <= 128) { // up to two 4^3-texel cells per lane
-                const float inv_xy = 1.0f / (float)ncxy, inv_x = 1.0f / (float)ncx;
+                const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
                 bool occ = false;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -519,11 +519,12 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         if (fits && !empty) {
             // ---- stage the box: rows along x, clamp-to-edge applied here --------------------------
             const int rows = ny * nz;
-            const float inv_ny = 1.0f / (float)ny;
+            const float inv_ny = __builtin_amdgcn_rcpf((float)ny);
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
             uint32_t seen = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
-            // lane / n for a wave-uniform n <= 64: (lane + 0.5)/n is at least 0.5/n away from an integer, far above f32 error
+            // lane / n for a wave-uniform n <= 64: (lane + 0.5)/n is at least 0.5/n away from an integer, far above the error of
+            // v_rcp_f32 (1 ulp; a correctly rounded division costs 12 VALU instructions here, once per chunk)
             if (ilo[0] >= 0 && ilo[0] + pitch <= (int)g.dim[0]) {
                 // rows lie inside the volume in x.  Source: the bricked copy; transport: LDS-DMA (global_load_lds_dwordx4),
                 // 16 bytes per lane straight into the tile, no VGPR round trip, no ds_write, every load of the box in
@@ -531,8 +532,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 // row ey) with LDS word ey*pitch + 4q = 4*lane, exactly the lane-linear image the DMA writes.  The per-lane
                 // source offset (brick column and row) is the same for every slice; the slice offset is scalar.
                 const int qpr = pitch >> 2;
-                const int rpw = (int)(64.0f / (float)qpr);
-                const int eyl = (int)(((float)lane + 0.5f) * (1.0f / (float)qpr)), q = (int)lane - eyl * qpr;
+                const int rpw = (int)(64.5f * __builtin_amdgcn_rcpf((float)qpr)); // = 64 / qpr for qpr in 1..16 (the half absorbs the 1-ulp rcp)
+                const int eyl = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)qpr)), q = (int)lane - eyl * qpr;
                 const uint32_t bx = ((uint32_t)ilo[0] >> 2) + (uint32_t)q;
                 const size_t zslab = (size_t)g.nbx * g.nby * 128u;   // bytes per brick layer (2 slices)
                 for (int eb = 0; eb * rpw < ny; ++eb) {
@@ -553,8 +554,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 seen = 0xff000000u; // the staged texels do not pass through registers: emptiness comes from the occupancy grid alone
             } else {
                 // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
-                const int rpi = (int)(64.0f / (float)pitch);
-                const int er = (int)(((float)lane + 0.5f) * (1.0f / (float)pitch)), ex = (int)lane - er * pitch;
+                const int rpi = (int)(64.5f * __builtin_amdgcn_rcpf((float)pitch));
+                const int er = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)pitch)), ex = (int)lane - er * pitch;
                 const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
                 const bool lane_on = er < rpi && ex < nx;
 #pragma unroll 4
