@@ -274,26 +274,18 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
 // ---------------------------------------------------------------------------------------------
 // Variant 1: per-wave LDS staging.
 //
-// One wave (= one 64-thread workgroup) owns an 8x8 pixel tile and marches its 64 rays in lockstep,
-// K steps at a time.  For each chunk of K steps the wave computes the axis-aligned box (in texel
-// space) that holds every texel any of its rays can touch during the chunk, copies that box --
-// clamp-to-edge already applied -- from the x-fastest global volume into LDS with row-coalesced
-// loads (lanes run along x), and then takes all 8*K gathers per ray from LDS: one global line is
-// touched once per chunk instead of once per corner per sample.  A box that does not fit the LDS
-// budget (far-away cameras: one pixel spans many voxels) falls back to global gathers for that
-// chunk.  The dt lattice, the sample positions and the in-box test are the same exact sequence as
-// in variant 0 / the oracle; only where the texels are read from differs.
+// One wave (= one 64-thread workgroup) owns an 8x8 pixel tile and marches its 64 rays in chunks.  Per chunk each lane
+// takes the number of steps (0..K) that brings it up to a plane across the wave's major axis; the wave computes the
+// axis-aligned box (in texel space) that holds every texel those steps can touch, skips the chunk if the occupancy grid
+// says the box is empty, otherwise copies the box from the bricked volume into its LDS tile by LDS-DMA and takes all
+// 8 gathers per sample from LDS.  A box that does not fit the tile (far-away cameras: one pixel spans many voxels)
+// falls back to global gathers for that chunk.  The dt lattice, the sample positions and the in-box test are the same
+// exact sequence as in variant 0 / the oracle; only where the texels are read from differs.
 // ---------------------------------------------------------------------------------------------
 // Wave64 min/max on the VALU's data-parallel-primitive path (no LDS traffic, unlike __shfl): two quad
 // permutes, two row mirrors, then row_bcast:15 / row_bcast:31 carry the row results upwards; lane 63 ends up
 // with the reduction over all 64 lanes and is read back into an SGPR.  Must run with all lanes enabled
 // (inactive rays pass the identity), which is how the kernel calls it.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL,
-                                                                 ROW_MASK, 0xF, false));
-}
 // The compiler turns update_dpp + fminf into mov, nop, mov_dpp, canonicalise, min per stage (26 VALU instructions per
 // reduction, and the chunk prologue does eight of them); written out, a stage is ONE v_min_f32_dpp whose first source is
 // the permuted copy of the register itself.  A DPP read of a VGPR needs two wait states after the VALU write of it:
@@ -311,36 +303,39 @@ __device__ __forceinline__ float wave_min(float v)
     asm volatile(VRM_DPP_STAGES("v_min_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-__device__ __forceinline__ float wave_max(float v)
-{
-    asm volatile(VRM_DPP_STAGES("v_max_f32_dpp") : "+v"(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 #undef VRM_DPP_STAGES
 // lo <- min over the wave of lo, hi <- max over the wave of hi, the two chains interleaved
-#define VRM_DPP_STAGE2(CTRL)                                          \
-    "v_min_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"              \
-    "v_max_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"              \
+#define VRM_DPP_STAGE2(T, CTRL)                                       \
+    "v_min_" T "_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_" T "_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"            \
     "s_nop 0\n\t"
+#define VRM_DPP_MINMAX(T)                                             \
+    "s_nop 1\n\t"                                                     \
+    VRM_DPP_STAGE2(T, "quad_perm:[1,0,3,2] row_mask:0xf")             \
+    VRM_DPP_STAGE2(T, "quad_perm:[2,3,0,1] row_mask:0xf")             \
+    VRM_DPP_STAGE2(T, "row_half_mirror row_mask:0xf")                 \
+    VRM_DPP_STAGE2(T, "row_mirror row_mask:0xf")                      \
+    VRM_DPP_STAGE2(T, "row_bcast:15 row_mask:0xa")                    \
+    VRM_DPP_STAGE2(T, "row_bcast:31 row_mask:0xc")                    \
+    "s_nop 0"
 __device__ __forceinline__ void wave_minmax(float &lo, float &hi)
 {
-    asm volatile("s_nop 1\n\t"
-                 VRM_DPP_STAGE2("quad_perm:[1,0,3,2] row_mask:0xf")
-                 VRM_DPP_STAGE2("quad_perm:[2,3,0,1] row_mask:0xf")
-                 VRM_DPP_STAGE2("row_half_mirror row_mask:0xf")
-                 VRM_DPP_STAGE2("row_mirror row_mask:0xf")
-                 VRM_DPP_STAGE2("row_bcast:15 row_mask:0xa")
-                 VRM_DPP_STAGE2("row_bcast:31 row_mask:0xc")
-                 "s_nop 0"
-                 : "+v"(lo), "+v"(hi));
+    asm volatile(VRM_DPP_MINMAX("f32") : "+v"(lo), "+v"(hi));
     lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 63));
     hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 63));
 }
+// the same on signed integers; the results come back wave-uniform (SGPRs)
+__device__ __forceinline__ void wave_minmax(int &lo, int &hi)
+{
+    asm volatile(VRM_DPP_MINMAX("i32") : "+v"(lo), "+v"(hi));
+    lo = __builtin_amdgcn_readlane(lo, 63);
+    hi = __builtin_amdgcn_readlane(hi, 63);
+}
+#undef VRM_DPP_MINMAX
 #undef VRM_DPP_STAGE2
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // global_load_dwordx4 only needs dword alignment
 
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
@@ -391,6 +386,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     // major axis m: per chunk a lane takes as many steps (0..K) as bring it up to the common plane, so the box is
     // the tile's cross-section times the chunk depth whatever the entry geometry.  Which lane takes which step in
     // which chunk does not change any lane's own dt sequence: the image is bit-identical.
+    // margin of the "interior chunk" test below: rounding of the one-FMA texel coordinate against the exact in-box test
+    float eps_in[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) eps_in[a] = 0.02f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
     int m_axis = 0;
     float sgn = 1.0f, smax = 0.0f;
     bool aligned;
@@ -455,25 +454,28 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane
         int n_lane;                  // steps of this lane in this chunk
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
-        float blo[3], bhi[3];
-        bool none, fits;
+        bool none, fits, interior;
         for (;;) {
             // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
             const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
             n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
+            bool margin_ok = true; // per lane: every step of this chunk stays inside the volume (slab) with margin
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test
-                const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
-                float mn = n_lane > 0 ? fminf(ua[a], ue) : __builtin_inff(), mx = n_lane > 0 ? fmaxf(ua[a], ue) : -__builtin_inff();
-                wave_minmax(mn, mx);
-                blo[a] = mn - 0.01f;
-                bhi[a] = mx + 0.01f;
+                // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test.
+                // The bounds are floored per lane and reduced as integers: the results land in SGPRs as they are.
                 // (z of a slab-partitioned volume: samples outside the slab's own range fail the test too, so a chunk
                 // that lies in another rank's slab degenerates to `none` and only advances dt)
-                ilo[a] = uni((int)floorf(fmaxf(blo[a], g.u_lo[a] - 0.5f)));
-                ihi[a] = uni((int)floorf(fminf(bhi[a], g.u_hi[a])) + 1);
+                const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
+                const float fl = fminf(ua[a], ue) - 0.01f, fh = fmaxf(ua[a], ue) + 0.01f;
+                int li = (int)floorf(fmaxf(fl, g.u_lo[a] - 0.5f)), hi = (int)floorf(fminf(fh, g.u_hi[a])) + 1;
+                if (n_lane <= 0) { li = 1 << 28; hi = -(1 << 28); }
+                else margin_ok = margin_ok && (fl - eps_in[a] >= g.u_lo[a]) && (fh + eps_in[a] <= g.u_hi[a]);
+                wave_minmax(li, hi);
+                ilo[a] = li;
+                ihi[a] = hi;
             }
+            interior = __builtin_amdgcn_ballot_w64(!margin_ok) == 0ull;
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-texel boundary: the staging loads are whole 16-byte quads of the bricked volume
             if (ilo[0] >= 0) ilo[0] &= ~3;
@@ -603,13 +605,6 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             // the box; the texel coordinate itself feeds continuous arithmetic only.  So a chunk whose whole box
             // lies inside the volume with margin ("interior", the common case) skips p and the test and takes
             // u = dt*(rd*scale) + (ro*scale + bias - box origin) in one FMA per axis.
-            bool interior = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float eps = 0.03f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-                interior = interior && (blo[a] - eps >= g.u_lo[a]) && (bhi[a] + eps <= g.u_hi[a]);
-            }
-            interior = uni(interior ? 1 : 0) != 0;
             const float fpx = (float)pitch, fsl = (float)slice;
             const float amax = (float)((nz - 2) * slice + (ny - 2) * pitch + (nx - 2)); // word address of the last corner cell
             auto steps = [&](auto interior_c) {
