@@ -297,6 +297,14 @@ def main():
                 "kernel": "march kernel (variant %d)" % a.kernel, "launches": int(launches),
                 "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
                 "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B}
+    # SURVEY.md 8(d) prices the voxels in the INPUT file's format (f32 RGBA = 16 B, f32 scalar = 4 B); the kernel
+    # reads the RGBA8 texels the reference's own texture holds (4 B), so `achieved`/`frac` above use 4 B (the
+    # lower figure). The survey-priced pair is carried beside it so either convention can be checked.
+    in_bytes = 16 if a.volume == "rgba" else 4
+    b_alg_survey = D * D * D * in_bytes + R * R * 4
+    ach_survey = achieved * b_alg_survey / b_alg_view
+    roofline["survey_8d"] = {"algorithmic_bytes_per_view": b_alg_survey, "achieved": round(ach_survey, 2),
+                             "frac": round(ach_survey / HBM_PEAK_GBS, 5)}
 
     out = {
         "metric": "views/s", "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,

@@ -228,6 +228,16 @@ VRM_API int vrm_compare_volume_f32_device(vrm_ctx *ctx, const float *color_czyx_
 VRM_API int vrm_image_ssd(vrm_image *a, vrm_image *b, uint64_t *out_ssd, uint64_t *out_count);
 VRM_API int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t n, uint64_t *out_ssd);
 
+/* skimage.metrics.structural_similarity(a, b, data_range=data_range, channel_axis=-1) on two uint8 images of
+ * width*height*channels interleaved host bytes (scripts/similarity.py:64-65; the caller forms data_range as the
+ * script does).  The scikit-image defaults are restated: 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample
+ * covariance, f64, 3-pixel border cropped, mean per channel and then over channels.  scikit-image is a dependency
+ * of the script that is absent from the reference tree and from this image, so this restates its published
+ * algorithm (Wang et al. 2004 as implemented in skimage >= 0.19): parity unpinned.  Images smaller than the
+ * window are VRM_ERR_INVALID (skimage raises ValueError). */
+VRM_API int vrm_ssim_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels,
+                        double data_range, double *out_ssim);
+
 /* skimage.io.imread (similarity.py:59-60) for the files this path writes and reads: 8-bit non-interlaced
  * gray / gray+alpha / RGB / RGBA PNG.  Always sets width, height, channels; with pixels == NULL that is all
  * (size query), otherwise decodes width*height*channels bytes, rows top to bottom, into pixels[capacity]. */

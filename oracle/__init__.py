@@ -209,3 +209,34 @@ def render_slab(voxels_zyxc, cam36, width, height, z_begin, z_end, attenuation=1
     lib().orc_render_slab(_p(v, ctypes.c_uint8), _p(dims, ctypes.c_uint32), _p(cam, ctypes.c_float), _p(tfw, ctypes.c_uint32),
                           ctypes.c_float(attenuation), width, height, int(z_begin), int(z_end), _p(out, ctypes.c_float), nt)
     return out
+
+
+def ssim_u8(img_a, img_b, data_range):
+    """skimage.metrics.structural_similarity(a, b, data_range=data_range, channel_axis=-1) for uint8 images, the
+    call of scripts/similarity.py:65, restated step by step from scikit-image's published implementation
+    (skimage/metrics/_structural_similarity.py, >= 0.19; Wang et al. 2004): float64 copies, scipy's
+    uniform_filter of size 7 on X, Y, X*X, Y*Y, X*Y, sample covariance NP/(NP-1), K1 = 0.01, K2 = 0.03, the map
+    cropped by (7-1)//2 and averaged per channel, then the mean over channels.  scikit-image is a dependency of
+    the script that is neither in the reference tree nor in this image: PARITY UNPINNED (no output of skimage
+    itself was available to check this against)."""
+    from scipy.ndimage import uniform_filter
+    a = np.asarray(img_a, dtype=np.uint8)
+    b = np.asarray(img_b, dtype=np.uint8)
+    assert a.shape == b.shape and a.ndim in (2, 3)
+    if a.ndim == 2:
+        a, b = a[:, :, None], b[:, :, None]
+    win, k1, k2 = 7, 0.01, 0.03
+    assert min(a.shape[:2]) >= win, "win_size exceeds image extent"
+    npx = win * win
+    cov_norm = npx / (npx - 1.0)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    pad = (win - 1) // 2
+    per_channel = []
+    for ch in range(a.shape[2]):
+        x, y = a[:, :, ch].astype(np.float64), b[:, :, ch].astype(np.float64)
+        ux, uy = uniform_filter(x, size=win), uniform_filter(y, size=win)
+        uxx, uyy, uxy = uniform_filter(x * x, size=win), uniform_filter(y * y, size=win), uniform_filter(x * y, size=win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+        per_channel.append(s[pad:-pad, pad:-pad].mean(dtype=np.float64))
+    return float(np.mean(per_channel))

@@ -86,6 +86,8 @@ extern "C" {
     pub fn vrm_compare_volume_f32_device(ctx: *mut vrm_ctx, color_czyx_device: *const f32, density_only: c_int, out_rmse: *mut f32) -> c_int;
     pub fn vrm_image_ssd(a: *mut vrm_image, b: *mut vrm_image, out_ssd: *mut u64, out_count: *mut u64) -> c_int;
     pub fn vrm_ssd_u8(ctx: *mut vrm_ctx, a: *const u8, b: *const u8, n: usize, out_ssd: *mut u64) -> c_int;
+    pub fn vrm_ssim_u8(ctx: *mut vrm_ctx, a: *const u8, b: *const u8, width: u32, height: u32, channels: u32, data_range: f64,
+                       out_ssim: *mut f64) -> c_int;
     pub fn vrm_png_read(path: *const c_char, width: *mut u32, height: *mut u32, channels: *mut u32, pixels: *mut u8, capacity: usize) -> c_int;
     // build extensions
     pub fn vrm_set_option(ctx: *mut vrm_ctx, option: c_int, value: i64) -> c_int;

@@ -111,3 +111,37 @@ def test_metric_formulas():
     assert mse == ssd / 4 and rmse == math.sqrt(mse)
     assert abs(psnr - 10 * math.log10(255.0 ** 2 / mse)) < 1e-12   # skimage: data_range 255 for uint8 (similarity.py:63)
     assert similarity.metrics_from_ssd(0, 4)[2] == math.inf
+
+
+def test_oracle_ssim_known_properties():
+    """The SSIM restatement (oracle.ssim_u8; parity unpinned, scikit-image is absent): identities that hold for
+    skimage's structural_similarity by construction."""
+    import oracle
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (20, 31, 4), dtype=np.uint8)
+    b = rng.integers(0, 256, (20, 31, 4), dtype=np.uint8)
+    assert oracle.ssim_u8(a, a, 255) == 1.0
+    s = oracle.ssim_u8(a, b, 255)
+    assert -1.0 <= s < 0.2                                           # independent noise
+    assert s == oracle.ssim_u8(b, a, 255)                            # symmetric
+    # the mean over channels of the per-channel values
+    per = [oracle.ssim_u8(a[:, :, c], b[:, :, c], 255) for c in range(4)]
+    assert abs(s - np.mean(per)) < 1e-15
+    # two constant images: every variance is zero, S = (2 ux uy + C1) / (ux^2 + uy^2 + C1)
+    x, y = np.full((9, 9), 100, np.uint8), np.full((9, 9), 140, np.uint8)
+    c1 = (0.01 * 255) ** 2
+    assert abs(oracle.ssim_u8(x, y, 255) - (2 * 100 * 140 + c1) / (100 ** 2 + 140 ** 2 + c1)) < 1e-12
+    # a 7x7 image has exactly one whole window: the sample statistics of the image itself
+    p, q = a[:7, :7, 0].astype(np.float64), b[:7, :7, 0].astype(np.float64)
+    c2 = (0.03 * 255) ** 2
+    cov = ((p - p.mean()) * (q - q.mean())).sum() / 48
+    want = ((2 * p.mean() * q.mean() + c1) * (2 * cov + c2)) / ((p.mean() ** 2 + q.mean() ** 2 + c1) * (p.var(ddof=1) + q.var(ddof=1) + c2))
+    assert abs(oracle.ssim_u8(a[:7, :7, 0], b[:7, :7, 0], 255) - want) < 1e-12
+
+
+def test_similarity_data_range_is_uint8_arithmetic():
+    from volume_renderer_amd import similarity
+    gt = np.array([[3, 200]], np.uint8)
+    approx = np.array([[5, 9]], np.uint8)
+    assert similarity.data_range_u8(gt, approx) == 195
+    assert similarity.data_range_u8(approx, np.array([[20, 30]], np.uint8)) == (9 - 20) % 256

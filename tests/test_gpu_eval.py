@@ -90,7 +90,7 @@ def test_image_ssd_matches_readback(rm1, vr, orc):
         im.close()
 
 
-def test_similarity_cli_table(rm1, vr, tmp_path):
+def test_similarity_cli_table(rm1, vr, orc, tmp_path):
     """Two tiny exports differing in attenuation -> the table of scripts/similarity.py, checked against numpy on Pillow's decode."""
     Image = pytest.importorskip("PIL.Image")
     from volume_renderer_amd import similarity
@@ -110,7 +110,7 @@ def test_similarity_cli_table(rm1, vr, tmp_path):
     avg = similarity.compare_dirs(rm1, d1, d2, x_div=4, y_div=3, out=out)
     lines = out.getvalue().strip().split("\n")
     assert lines[0] == "filename, mse, rmse, psnr, ssim" and len(lines) == 1 + 4 * 2 + 1
-    tot = np.zeros(3)
+    tot = np.zeros(4)
     k = 1
     for ix in range(4):                                           # itertools.product(range(x), range(1, y)) order
         for iy in range(1, 3):
@@ -121,7 +121,46 @@ def test_similarity_cli_table(rm1, vr, tmp_path):
             f = lines[k].split(", ")
             assert f[0] == name and float(f[1]) == mse and float(f[2]) == math.sqrt(mse)
             assert abs(float(f[3]) - 10 * math.log10(255.0 ** 2 / mse)) < 1e-9
-            tot += (mse, math.sqrt(mse), 10 * math.log10(255.0 ** 2 / mse))
+            ua, ub = ga.astype(np.uint8), gb.astype(np.uint8)
+            ssim = orc.ssim_u8(ua, ub, similarity.data_range_u8(ua, ub))
+            assert abs(float(f[4]) - ssim) < 1e-12 and 0.0 < ssim < 1.0
+            tot += (mse, math.sqrt(mse), 10 * math.log10(255.0 ** 2 / mse), ssim)
             k += 1
-    assert np.allclose(avg, tot / 8, rtol=1e-12)
+    assert np.allclose(avg, tot / 8, rtol=1e-12, atol=1e-12)
     assert lines[-1].startswith("average, ")
+
+
+@pytest.mark.parametrize("shape", [(7, 7), (7, 7, 4), (20, 31, 4), (33, 9, 3), (64, 48, 1), (257, 130, 2)])
+def test_ssim_u8_matches_oracle(rm1, orc, shape):
+    """vrm_ssim_u8 (exact integer window sums) against the scipy restatement (running f64 means): 1e-12."""
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(0, 256, shape, dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-40, 41, shape), 0, 255).astype(np.uint8)
+    for dr in (255, 180):
+        got, want = rm1.ssim_u8(a, b, dr), orc.ssim_u8(a, b, dr)
+        assert abs(got - want) < 1e-12, (got, want)
+    assert rm1.ssim_u8(a, a, 255) == 1.0
+
+
+def test_ssim_u8_rendered_images_and_errors(rm1, vr, orc):
+    dims = (32, 32, 32)
+    g = rm1.voxel_grid
+    g.new(dims)
+    g.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32(dims)))
+    cam = vr.uniform_from_array(sphere_cam(orc, 1, 3))
+    imgs = []
+    for att in (1.0, 3.0):
+        s = vr.Screenshotter(rm1, 96, 80)
+        g.attenuation = att
+        g.update_voxel_grid_buffer()
+        rm1.draw(cam, s)
+        imgs.append(s.read())
+        s.close()
+    from volume_renderer_amd import similarity
+    dr = similarity.data_range_u8(imgs[0], imgs[1])
+    got, want = rm1.ssim_u8(imgs[0], imgs[1], dr), orc.ssim_u8(imgs[0], imgs[1], dr)
+    assert 0.0 < got < 1.0 and abs(got - want) < 1e-12
+    with pytest.raises(vr.VrmError):
+        rm1.ssim_u8(np.zeros((6, 20, 4), np.uint8), np.zeros((6, 20, 4), np.uint8), 255)      # smaller than the window
+    with pytest.raises(ValueError):
+        rm1.ssim_u8(np.zeros((8, 8), np.uint8), np.zeros((8, 9), np.uint8), 255)

@@ -360,6 +360,19 @@ class RayMarcher:
         _ffi.check(_ffi.lib().vrm_ssd_u8(self._h, a.ctypes.data, b.ctypes.data, a.size, ctypes.byref(out)))
         return out.value
 
+    def ssim_u8(self, a, b, data_range):
+        """skimage.metrics.structural_similarity(a, b, data_range=data_range, channel_axis=-1) for two uint8 images
+        of shape (h, w) or (h, w, c), c <= 4 (similarity.py:65; GPU reduction, scikit-image defaults restated)."""
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        if a.shape != b.shape or a.ndim not in (2, 3):
+            raise ValueError(f"need two (h, w[, c]) images of one shape, got {a.shape} and {b.shape}")
+        h, w = a.shape[:2]
+        c = a.shape[2] if a.ndim == 3 else 1
+        out = ctypes.c_double()
+        _ffi.check(_ffi.lib().vrm_ssim_u8(self._h, a.ctypes.data, b.ctypes.data, w, h, c, float(data_range), ctypes.byref(out)))
+        return out.value
+
     def image_ssd(self, img_a, img_b):
         """SSD of two rendered images on the device -> (ssd, number of channel values)."""
         ssd, cnt = ctypes.c_uint64(), ctypes.c_uint64()

@@ -99,6 +99,8 @@ SYMBOLS = {
     "vrm_compare_volume_f32_device": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _f32p]),
     "vrm_image_ssd": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "vrm_ssd_u8": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]),
+    "vrm_ssim_u8": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
+                                   ctypes.POINTER(ctypes.c_double)]),
     "vrm_png_read": (ctypes.c_int, [ctypes.c_char_p, _u32p, _u32p, _u32p, _vp, ctypes.c_size_t]),
     "vrm_last_error": (ctypes.c_char_p, []),
     "vrm_version": (ctypes.c_char_p, []),

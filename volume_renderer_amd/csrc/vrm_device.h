@@ -76,6 +76,9 @@ hipError_t vrm_launch_compare_volume(const uint32_t *vox, const float *data_czyx
                                      const float tf9[9], double *partial, uint32_t blocks, hipStream_t stream);
 hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_words, size_t rows, size_t pitch_a, size_t pitch_b,
                              unsigned long long *partial, uint32_t blocks, hipStream_t stream);
+// a, b: width*height*channels interleaved bytes, width and height >= 7; items = (width-6)*(height-6)*channels
+hipError_t vrm_launch_ssim_u8(const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels, double c1,
+                              double c2, double *partial, uint32_t blocks, hipStream_t stream);
 
 // sort-last compositing: the part of a view the compositing kernel needs (the sign of rd.z per pixel)
 struct VrmCompositeView {

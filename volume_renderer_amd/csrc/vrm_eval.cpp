@@ -105,6 +105,36 @@ extern "C" int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size
     return ssd_device(ctx, (const uint8_t *)da.p, (const uint8_t *)db.p, padded / 4, 1, padded, padded, out_ssd);
 }
 
+extern "C" int vrm_ssim_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels,
+                           double data_range, double *out_ssim)
+{
+    REQUIRE(ctx != nullptr && a != nullptr && b != nullptr && out_ssim != nullptr, "null argument");
+    REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4, got %u", channels);
+    // skimage: "win_size exceeds image extent" (win_size = 7)
+    REQUIRE(width >= 7 && height >= 7, "image %ux%u is smaller than the 7x7 SSIM window", width, height);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)width * height * channels;
+    DevBuf da, db, partial;
+    HIP_TRY(hipMalloc(&da.p, bytes));
+    HIP_TRY(hipMalloc(&db.p, bytes));
+    HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const size_t items = (size_t)(width - 6) * (height - 6) * channels;
+    const uint32_t blocks = vrm_reduce_blocks(items);
+    HIP_TRY(hipMalloc(&partial.p, blocks * sizeof(double)));
+    const double c1 = (0.01 * data_range) * (0.01 * data_range), c2 = (0.03 * data_range) * (0.03 * data_range);
+    HIP_TRY(vrm_launch_ssim_u8((const uint8_t *)da.p, (const uint8_t *)db.p, width, height, channels, c1, c2, (double *)partial.p, blocks,
+                               ctx->stream));
+    std::vector<double> h(blocks);
+    HIP_TRY(hipMemcpyAsync(h.data(), partial.p, blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (double v : h) sum += v; // fixed order: deterministic
+    // per-channel means over the cropped map, then the mean over channels: every channel has the same count
+    *out_ssim = sum / (double)items;
+    return VRM_OK;
+}
+
 extern "C" int vrm_image_ssd(vrm_image *a, vrm_image *b, uint64_t *out_ssd, uint64_t *out_count)
 {
     REQUIRE(a != nullptr && b != nullptr && out_ssd != nullptr, "null argument");

@@ -931,6 +931,46 @@ __global__ void __launch_bounds__(256) ssd_u8_kernel(const uint8_t *__restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// skimage.metrics.structural_similarity as similarity.py:65 calls it (uint8 images, channel_axis=-1, defaults
+// otherwise): 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance (49/48), f64 arithmetic, the 3-pixel
+// border cropped before the mean -- so only whole windows count and the filter's edge mode never shows. One item =
+// one (interior pixel, channel); the five window sums are exact integers (skimage's are f64 running means of the
+// same integers), the SSIM term is formed in f64 and summed per block.
+__global__ void __launch_bounds__(256) ssim_u8_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint32_t width,
+                                                      uint32_t height, uint32_t channels, double c1, double c2,
+                                                      double *__restrict__ partial)
+{
+    const uint32_t iw = width - 6u, ih = height - 6u;
+    const size_t n = (size_t)iw * ih * channels, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t pitch = (size_t)width * channels;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t c = (uint32_t)(i % channels);
+        const size_t px = i / channels;
+        const uint32_t x = (uint32_t)(px % iw), y = (uint32_t)(px / iw);
+        uint32_t sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (uint32_t dy = 0; dy < 7u; ++dy) {
+            const size_t row = (size_t)(y + dy) * pitch + (size_t)x * channels + c;
+#pragma unroll
+            for (uint32_t dx = 0; dx < 7u; ++dx) {
+                const uint32_t va = a[row + dx * channels], vb = b[row + dx * channels];
+                sx += va;
+                sy += vb;
+                sxx += va * va;
+                syy += vb * vb;
+                sxy += va * vb;
+            }
+        }
+        const double ux = (double)sx / 49.0, uy = (double)sy / 49.0;
+        const double uxx = (double)sxx / 49.0, uyy = (double)syy / 49.0, uxy = (double)sxy / 49.0;
+        const double cov_norm = 49.0 / 48.0;
+        const double vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+        const double a1 = 2.0 * ux * uy + c1, a2 = 2.0 * vxy + c2, b1 = ux * ux + uy * uy + c1, b2 = vx + vy + c2;
+        acc += (a1 * a2) / (b1 * b2);
+    }
+    block_sum_store(acc, partial);
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(uint32_t *dst, size_t n, uint32_t value)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1068,6 +1108,13 @@ hipError_t vrm_launch_ssd_u8(const uint8_t *a, const uint8_t *b, size_t row_word
                              unsigned long long *partial, uint32_t blocks, hipStream_t stream)
 {
     hipLaunchKernelGGL(ssd_u8_kernel, dim3(blocks), dim3(256), 0, stream, a, b, row_words, rows, pitch_a, pitch_b, partial);
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_ssim_u8(const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels, double c1,
+                              double c2, double *partial, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssim_u8_kernel, dim3(blocks), dim3(256), 0, stream, a, b, width, height, channels, c1, c2, partial);
     return hipGetLastError();
 }
 

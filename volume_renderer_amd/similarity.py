@@ -7,9 +7,12 @@ Per file `<ix>-<iy>.png` (ix in 0..x_div-1, iy in 1..y_div-1, the reference's it
 mse = mean squared error over every channel value of the two uint8 images (skimage.metrics.mean_squared_error,
 f64), rmse = sqrt(mse), psnr = 10*log10(255^2 / mse) (skimage's data_range for uint8 input); then the averages.
 The PNGs are decoded by vrm_png_read and the sum of squared differences is an exact integer reduction on the
-GPU (vrm_ssd_u8), so mse is bit-identical to skimage's.  SSIM is NOT computed: skimage is not available where
-this was written, so a restatement of structural_similarity (with the reference's idiosyncratic
-data_range = img_gt.max() - img_approx.min(), similarity.py:64) could not be pinned; the column prints `nan`.
+GPU (vrm_ssd_u8), so mse is bit-identical to skimage's.  ssim = structural_similarity(img_gt, img_approx,
+data_range = img_gt.max() - img_approx.min(), channel_axis=-1) (similarity.py:64-65; the data range is the
+script's own, formed in uint8 arithmetic as numpy forms it) through vrm_ssim_u8, which restates scikit-image's
+published defaults (7x7 uniform window, K1 0.01, K2 0.03, sample covariance, f64, cropped border).  scikit-image
+is not available where this was written: the SSIM column is checked against an independent scipy restatement
+only -- parity unpinned.  A 2-D (gray) image counts as one channel.
 """
 import argparse
 import ctypes
@@ -40,9 +43,14 @@ def metrics_from_ssd(ssd, count):
     return mse, rmse, psnr
 
 
+def data_range_u8(img_gt, img_approx):
+    """similarity.py:64: `img_gt.max() - img_approx.min()` on uint8 arrays, i.e. modulo 256 as numpy computes it."""
+    return (int(img_gt.max()) - int(img_approx.min())) & 0xFF
+
+
 def compare_dirs(ray_marcher, dir_gt, dir_approx, x_div=8, y_div=8, out=sys.stdout):
-    """similarity.py:47-80.  Returns the (mse, rmse, psnr) averages."""
-    tot = [0.0, 0.0, 0.0]
+    """similarity.py:47-80.  Returns the (mse, rmse, psnr, ssim) averages."""
+    tot = [0.0, 0.0, 0.0, 0.0]
     n = 0
     print("filename, mse, rmse, psnr, ssim", file=out)
     for ix in range(x_div):
@@ -52,13 +60,13 @@ def compare_dirs(ray_marcher, dir_gt, dir_approx, x_div=8, y_div=8, out=sys.stdo
             b = png_read(os.path.join(dir_approx, name))
             if a.shape != b.shape:
                 raise ValueError(f"{name}: shapes differ, {a.shape} vs {b.shape}")
-            m = metrics_from_ssd(ray_marcher.ssd_u8(a, b), a.size)
-            for k in range(3):
+            m = metrics_from_ssd(ray_marcher.ssd_u8(a, b), a.size) + (ray_marcher.ssim_u8(a, b, data_range_u8(a, b)),)
+            for k in range(4):
                 tot[k] += m[k]
             n += 1
-            print(f"{name}, {m[0]}, {m[1]}, {m[2]}, nan", file=out)
+            print(f"{name}, {m[0]}, {m[1]}, {m[2]}, {m[3]}", file=out)
     avg = [t / n for t in tot]
-    print(f"average, {avg[0]}, {avg[1]}, {avg[2]}, nan", file=out)
+    print(f"average, {avg[0]}, {avg[1]}, {avg[2]}, {avg[3]}", file=out)
     return tuple(avg)
 
 
