@@ -92,7 +92,8 @@ def run_c5(a):
     rm.synchronize()
     march_ms = (time.perf_counter() - t1) * 1e3
     stored = slr.s1 - slr.s0
-    b_alg_view = dims[0] * dims[1] * stored * 4 + R * R * 16      # this rank: its slab read once, its f32 partial written once
+    # this rank: its slab read once (scalar volume: the packed alpha copy, 1 B per voxel), its f32 partial written once
+    b_alg_view = dims[0] * dims[1] * stored * 1 + R * R * 16
     achieved = b_alg_view * B / (march_ms * 1e-3) / 1e9
     out = {
         "metric": "views/s", "value": round(len(cams) * a.steps / elapsed, 3), "unit": "views/s", "n_gpus": world, "steps": a.steps,
@@ -278,7 +279,9 @@ def main():
 
     # ---- roofline of the march kernel on this rank: algorithmic bytes = every voxel read once (4 B, the
     # reference's own texel format) + every RGBA8 pixel written once, per view -------------
-    b_alg_view = D * D * D * 4 + R * R * 4
+    # (the 1-channel march -- scalar volume or transfer function -- reads the packed alpha copy: 1 B per voxel)
+    vox_bytes = 1 if (a.volume != "rgba" or a.tf) else 4
+    b_alg_view = D * D * D * vox_bytes + R * R * 4
     views_timed = len(my_cams) * a.steps
     achieved = (b_alg_view * views_timed / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else 0.0
     # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3 around the process): the figure comes
@@ -287,7 +290,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}"
+        key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}" + (":tf" if a.tf else "")
         if key in tj:
             traffic = int(tj[key]["hbm_bytes_per_view"] * B)
     except (OSError, ValueError, KeyError):

@@ -253,7 +253,10 @@ typedef enum vrm_option {
                                  sampled; they contribute exactly 0, so the image is bit-identical to 0 (tests) */
     VRM_OPT_PROFILE = 2,      /* default 0; 1: record hipEvents around every march launch (vrm_profile_read) */
     VRM_OPT_DIAGNOSTICS = 3,  /* default 0; 1: also write per-pixel f32 colour, iteration counts and ray geometry */
-    VRM_OPT_CHUNK_STEPS = 4   /* default 0 = automatic; n: march steps per LDS-staged box (tuning, no effect on the image) */
+    VRM_OPT_CHUNK_STEPS = 4,  /* default 0 = automatic; n: march steps per LDS-staged box (tuning, no effect on the image) */
+    VRM_OPT_PACKED_ALPHA = 5  /* 1-channel march (scalar volumes, transfer function) staged from the packed alpha copy of
+                                 the volume, one byte per texel: 1 = on (default), 0 = stage the RGBA8 texels instead (tuning; same
+                                 image to f32 rounding) */
 } vrm_option;
 VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
 VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);

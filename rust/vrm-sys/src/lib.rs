@@ -37,6 +37,7 @@ pub const VRM_OPT_SKIP_EMPTY: c_int = 1;
 pub const VRM_OPT_PROFILE: c_int = 2;
 pub const VRM_OPT_DIAGNOSTICS: c_int = 3;
 pub const VRM_OPT_CHUNK_STEPS: c_int = 4;
+pub const VRM_OPT_PACKED_ALPHA: c_int = 5;
 
 extern "C" {
     // RayMarcher (ray_marcher/mod.rs:18-142)

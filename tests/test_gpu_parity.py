@@ -269,3 +269,53 @@ def test_production_kernel_equals_diagnostics_kernel(rm, vr, orc):
             a = draw(rm, vr, cam, 100, 84, diag=True)["rgba8"]
             b = draw(rm, vr, cam, 100, 84, diag=False)["rgba8"]
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("packed", [1, 0])
+def test_parity_one_channel_march_both_staging_sources(rm, vr, orc, packed):
+    """The 1-channel march (scalar volumes, transfer function) stages either the packed alpha bricks (default) or the
+    RGBA8 bricks (VRM_OPT_PACKED_ALPHA = 0): both against the oracle, on dims off the 16-texel packed brick grid,
+    thin volumes, ragged images and a camera inside the volume."""
+    rm.set_option(vr.OPT_PACKED_ALPHA, packed)
+    try:
+        cases = [((37, 21, 19), 6.0, False, 72, 56, 2.5), ((16, 16, 16), 3.0, True, 64, 64, 2.5), ((65, 3, 3), 30.0, False, 50, 37, 30.0),
+                 ((1, 1, 1), 80.0, False, 24, 24, 3.0), ((50, 7, 33), 12.0, True, 65, 16, 9.0), ((15, 17, 16), 9.0, False, 33, 70, 1.9)]
+        for dims, att, use_tf, W, H, radius in cases:
+            sc = synth.blobs_scalar_u8(dims) if min(dims) >= 8 else np.random.default_rng(sum(dims)).integers(0, 256, dims[::-1], dtype=np.uint8)
+            vox = np.repeat(np.ascontiguousarray(sc)[..., None], 4, 3)
+            configure(rm, vox, att, use_tf)
+            for ix, iy in [(1, 3), (6, 5)]:
+                cam = sphere_cam(orc, ix, iy, radius=radius, aspect=W / H)
+                got = draw(rm, vr, cam, W, H)
+                check(orc, got, vox, cam, W, H, att, use_tf)
+        # the transfer function on a volume that is NOT scalar reads the alpha channel only (wgsl:145-147)
+        vox = synth.random_rgba8((23, 18, 35), 11)
+        configure(rm, vox, 15.0, True)
+        cam = sphere_cam(orc, 3, 2)
+        check(orc, draw(rm, vr, cam, 80, 64), vox, cam, 80, 64, 15.0, True)
+        # camera inside the volume
+        sc = synth.blobs_scalar_u8((40, 40, 40))
+        vox = np.repeat(sc[..., None], 4, 3)
+        configure(rm, vox, 5.0, False)
+        cam = orc.camera_uniform((0.1, 0.05, -0.2), target=(0.4, 0.3, 0.5))
+        check(orc, draw(rm, vr, cam, 64, 64), vox, cam, 64, 64, 5.0, False)
+    finally:
+        rm.set_option(vr.OPT_PACKED_ALPHA, 1)
+
+
+def test_one_channel_staging_sources_agree(rm, vr, orc):
+    """Packed and RGBA staging feed the same arithmetic the same values: equal iteration counts, f32 accumulators equal
+    to rounding of the texel coordinate (the staged box has another origin)."""
+    sc = synth.blobs_scalar_u8((72, 60, 52))
+    vox = np.repeat(sc[..., None], 4, 3)
+    configure(rm, vox, 8.0, False)
+    cam = sphere_cam(orc, 5, 2)
+    out = []
+    for packed in (1, 0):
+        rm.set_option(vr.OPT_PACKED_ALPHA, packed)
+        out.append(draw(rm, vr, cam, 128, 96))
+    rm.set_option(vr.OPT_PACKED_ALPHA, 1)
+    assert np.array_equal(out[0]["iters"], out[1]["iters"])
+    assert np.abs(out[0]["f32"] - out[1]["f32"]).max() < 1e-5
+    assert np.abs(out[0]["rgba8"].astype(int) - out[1]["rgba8"].astype(int)).max() <= 1
+    assert out[0]["rgba8"][..., 3].max() > 50

@@ -21,6 +21,8 @@ ap.add_argument("--tf", action="store_true")
 ap.add_argument("--radius", type=float, default=2.5)
 ap.add_argument("--xdiv", type=int, default=8)
 ap.add_argument("--ydiv", type=int, default=5)
+ap.add_argument("--packed-a", type=int, default=1, help="VRM_OPT_PACKED_ALPHA for side a")
+ap.add_argument("--packed-b", type=int, default=1, help="VRM_OPT_PACKED_ALPHA for side b")
 a = ap.parse_args()
 dims = tuple(a.dim * 3) if len(a.dim) == 1 else tuple(a.dim)
 W, H = (a.res * 2)[:2]
@@ -43,8 +45,9 @@ for (ix, iy) in vr.sphere_views(a.xdiv, a.ydiv):
     ctl.update_position(camera)
     cam = camera.uniform()
     imgs = []
-    for k in (a.a, a.b):
+    for k, pk in ((a.a, a.packed_a), (a.b, a.packed_b)):
         rm.set_option(vr.OPT_KERNEL, k)
+        rm.set_option(vr.OPT_PACKED_ALPHA, pk)
         s = vr.Screenshotter(rm, W, H)
         rm.draw(cam, s)
         imgs.append(s.read().astype(np.int32))

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--tf", action="store_true")
     ap.add_argument("--att", type=float, default=1.0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--packed", type=int, default=1, help="VRM_OPT_PACKED_ALPHA")
     ap.add_argument("--xdiv", type=int, default=16)
     ap.add_argument("--ydiv", type=int, default=17)
     ap.add_argument("--ix", type=int, default=-1, help="only the views of this azimuth index")
@@ -36,6 +37,7 @@ def main():
     rm.set_option(vr.OPT_KERNEL, a.kernel)
     rm.set_option(vr.OPT_SKIP_EMPTY, a.skip)
     rm.set_option(vr.OPT_CHUNK_STEPS, a.chunk)
+    rm.set_option(vr.OPT_PACKED_ALPHA, a.packed)
     if a.scalar:
         s = synth.blobs_scalar_u8((D, D, D))
         rm.voxel_grid.upload_scalar(s.reshape(-1), (D, D, D), 1)
@@ -78,7 +80,7 @@ def main():
                 ms, n = rm.profile_read()
                 per.append(ms / len(part))
             tot = sum(p * min(a.views, len(cams) - i * a.views) for i, p in enumerate(per))
-            print(f"kernel {a.kernel} skip {a.skip} chunk {a.chunk}: all {len(cams)} views {R}^2 of {D}^3: {tot:.1f} ms => "
+            print(f"kernel {a.kernel} skip {a.skip} chunk {a.chunk} packed {a.packed}: all {len(cams)} views {R}^2 of {D}^3: {tot:.1f} ms => "
                   f"{tot / len(cams):.3f} ms/view, {n_ref / tot / 1e6:.1f} Gsamples/s; ms/view per launch: "
                   + " ".join(f"{p:.2f}" for p in per), flush=True)
         return

@@ -17,6 +17,7 @@ OPT_SKIP_EMPTY = 1
 OPT_PROFILE = 2
 OPT_DIAGNOSTICS = 3
 OPT_CHUNK_STEPS = 4
+OPT_PACKED_ALPHA = 5
 
 
 class VrmError(RuntimeError):

@@ -75,6 +75,10 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     if (ctx->bricks) HIP_TRY(hipFree(ctx->bricks));
     ctx->bricks = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
+    if (ctx->abricks) HIP_TRY(hipFree(ctx->abricks));
+    ctx->abricks = nullptr;
+    const uint32_t xyz[3] = {x, y, z};
+    HIP_TRY(hipMalloc((void **)&ctx->abricks, vrm_alpha_bricks_bytes(xyz)));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
     ctx->gdim[0] = x; ctx->gdim[1] = y; ctx->gdim[2] = z;
@@ -90,6 +94,7 @@ static int grid_reset_contents(vrm_ctx *ctx)
     HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
     HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
     HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
+    HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, ctx->dim, ctx->abricks, ctx->stream));
     ctx->scalar = false;
     ctx->attenuation = 1.0f;   // grid.rs:100,197
     tf_defaults(&ctx->tf);     // grid.rs:198
@@ -184,6 +189,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
     if (ctx->vox) (void)hipFree(ctx->vox);
     if (ctx->occ) (void)hipFree(ctx->occ);
     if (ctx->bricks) (void)hipFree(ctx->bricks);
+    if (ctx->abricks) (void)hipFree(ctx->abricks);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     if (ctx->views_dev) (void)hipFree(ctx->views_dev);
     if (ctx->views_host) (void)hipHostFree(ctx->views_host);
@@ -197,6 +203,7 @@ static int grid_finish_upload(vrm_ctx *ctx)
 {
     HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
     HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
+    HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, ctx->dim, ctx->abricks, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->flag_dev, 0, 4, ctx->stream));
     HIP_TRY(vrm_launch_detect_nonscalar(ctx->vox, ctx->vox_words, ctx->flag_dev, ctx->stream));
     uint32_t flag = 1;
@@ -481,6 +488,8 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     g.occ = ctx->occ;
     g.bricks = ctx->bricks;
     g.nbx = (ctx->dim[0] + 3) / 4;
+    g.abricks = ctx->abricks;
+    g.nbxa = (ctx->dim[0] + 15) / 16;
     g.nby = (ctx->dim[1] + 3) / 4;
     for (int i = 0; i < 3; ++i) {
         g.dim[i] = ctx->dim[i];
@@ -517,6 +526,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     }
     p->use_tf = ctx->tf.use_transfer_function[0] != 0 ? 1u : 0u;
     p->chunk_steps = (uint32_t)ctx->opt_chunk;
+    p->packed_alpha = (int32_t)ctx->opt_packed;
 }
 
 extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
@@ -702,6 +712,7 @@ extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
     case VRM_OPT_PROFILE: ctx->opt_profile = value; break;
     case VRM_OPT_DIAGNOSTICS: ctx->opt_diag = value; break;
     case VRM_OPT_CHUNK_STEPS: ctx->opt_chunk = value < 0 ? 0 : (value > 256 ? 256 : value); break;
+    case VRM_OPT_PACKED_ALPHA: ctx->opt_packed = value != 0 ? 1 : 0; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;
@@ -716,6 +727,7 @@ extern "C" int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value)
     case VRM_OPT_PROFILE: *value = ctx->opt_profile; break;
     case VRM_OPT_DIAGNOSTICS: *value = ctx->opt_diag; break;
     case VRM_OPT_CHUNK_STEPS: *value = ctx->opt_chunk; break;
+    case VRM_OPT_PACKED_ALPHA: *value = ctx->opt_packed; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;

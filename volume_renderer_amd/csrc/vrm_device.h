@@ -30,6 +30,12 @@ struct VrmGridDev {
     // A staged box of ~12^3 texels touches ~90 lines of it instead of ~190 of the x-fastest array.
     const uint32_t *bricks;
     uint32_t nbx, nby;
+    // the alpha channel alone, four x-adjacent texels per word (byte k = texel 4*xw + k), bricked the same way over
+    // the packed words: brick = 4 words (16 texels of x) x 4(y) x 2(z) = one 128-byte line, nbxa = ceil(X / 16)
+    // bricks along x, nby along y; texels past the volume's edge repeat the edge (clamp-to-edge).  Staging source of
+    // the 1-channel march (scalar volumes, transfer function): a quarter of the bytes of `bricks`.
+    const uint32_t *abricks;
+    uint32_t nbxa;
     float box_min[3];    // VoxelGridUniform.box_min (grid.rs:271)
     float box_max[3];    // box_min + box_size, rounded as the shader computes it (wgsl:202,250)
     float box_size[3];
@@ -55,7 +61,8 @@ struct VrmMarchParams {
     float attenuation;   // voxel_grid.buffer[0] (wgsl:150)
     float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
     uint32_t use_tf;
-    uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 6 texels of depth)
+    uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 8 texels of depth)
+    int32_t packed_alpha; // 1-channel march staged from the packed alpha bricks (default) or, 0, from the RGBA8 bricks
 };
 
 // launchers implemented in vrm_kernels.hip
@@ -63,6 +70,9 @@ hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int varia
                             hipStream_t stream);
 hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream);
 hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *bricks, hipStream_t stream);
+// bytes of the packed alpha bricks of a dim[0] x dim[1] x dim[2] volume, and their builder
+size_t vrm_alpha_bricks_bytes(const uint32_t dim[3]);
+hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream);
 hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream);
 hipError_t vrm_launch_quantize_f32(const float *src_czyx, uint32_t channels, size_t n_voxels, uint32_t *dst, hipStream_t stream);
 hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sample, size_t n_voxels, uint32_t *dst,

@@ -23,6 +23,7 @@ struct vrm_ctx {
     bool scalar = false;     // r == g == b == a everywhere
     uint8_t *occ = nullptr;  // max alpha per 8^3 cell, rebuilt whenever the voxels change
     uint32_t *bricks = nullptr; // the same voxels in 4x4x2-texel bricks of one 128-byte line each (staging source)
+    uint32_t *abricks = nullptr; // the alpha channel alone, 4 texels per word, bricked (1-channel march staging source)
     float attenuation = 1.0f;
     vrm_transfer_function tf;
     uint32_t *flag_dev = nullptr; // 1 word scratch for detect_nonscalar
@@ -34,7 +35,7 @@ struct vrm_ctx {
     hipEvent_t views_free = nullptr;   // signalled when the last batch's descriptor upload was consumed
 
     // options
-    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0;
+    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1;
 
     // profiling (VRM_OPT_PROFILE)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -169,6 +169,42 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     return acc.alpha >= 1.0f;
 }
 
+// The 1-channel march from the packed alpha copy (VrmGridDev::abricks): w[i] holds texel x of row i in byte 0 and
+// texel x+1 in byte 1 (rows: y0z0, y1z0, y0z1, y1z1).  Same arithmetic on the same values as shade<true, USE_TF>.
+template <bool USE_TF>
+__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
+                                             Accum &acc)
+{
+    const float wxs = wx * 0x1p127f;
+    auto xlerp = [&](uint32_t t) -> float {
+        float d; // (byte 1) - (byte 0) as the exact denormal difference
+        asm("v_sub_f32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "=v"(d) : "v"(t));
+        return __builtin_fmaf(d, wxs, byte_scaled<0>(t));
+    };
+    const float c00 = xlerp(w[0]), c10 = xlerp(w[1]), c01 = xlerp(w[2]), c11 = xlerp(w[3]);
+    const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
+    const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
+    const float a255 = __builtin_fmaf(wz, c1 - c0, c0) * T22;
+    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
+    const float om = 1.0f - acc.alpha;
+    const float wgt = om * alpha_src;
+    if (USE_TF) {
+        const float a = a255 * (1.0f / 255.0f);
+        const bool hi = a >= 0.5f;
+        const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
+        const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
+        const float s1 = hi ? P.col_b[1] : P.col_a[1], e1 = hi ? P.col_c[1] : P.col_b[1];
+        const float s2 = hi ? P.col_b[2] : P.col_a[2], e2 = hi ? P.col_c[2] : P.col_b[2];
+        acc.cr = __builtin_fmaf(wgt, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
+        acc.cg = __builtin_fmaf(wgt, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
+        acc.cb = __builtin_fmaf(wgt, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
+    } else {
+        acc.cr = __builtin_fmaf(wgt, a255, acc.cr); // r == g == b == a for scalar volumes
+    }
+    acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
+    return acc.alpha >= 1.0f;
+}
+
 template <bool ALPHA_ONLY, bool USE_TF>
 __device__ __forceinline__ void finish_colour(Accum &acc)
 {
@@ -337,9 +373,12 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
+    // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
+    // four x-adjacent texels instead of one RGBA8 texel: a quarter of the staging bytes and of the tile's x extent.
+    static_assert(!PACKED || ALPHA_ONLY, "the packed source holds the alpha channel only");
     // LDS tile layout, chosen per chunk: rows along x with pitch = the box's x extent rounded up to 4 texels
     // (16-byte staging stores), slices along z with pitch = ny * pitch rounded up to 4 (mod 8) words, which keeps
     // the 32-lane gather groups spread over the 32 banks for every view direction (DESIGN.md "LDS layout").
@@ -454,6 +493,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane
         int n_lane;                  // steps of this lane in this chunk
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
+        int x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
         bool none, fits, interior;
         for (;;) {
             // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
@@ -477,13 +517,16 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             }
             interior = __builtin_amdgcn_ballot_w64(!margin_ok) == 0ull;
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
-            // rows start on a 4-texel boundary: the staging loads are whole 16-byte quads of the bricked volume
-            if (ilo[0] >= 0) ilo[0] &= ~3;
-            nx = ihi[0] - ilo[0] + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
+            // rows start on a 4-unit boundary: the staging loads are whole 16-byte quads of the bricked volume
+            x0u = PACKED ? ilo[0] >> 2 : ilo[0];
+            if (x0u >= 0) x0u &= ~3;
+            if (!PACKED) ilo[0] = x0u;
+            nx = (PACKED ? ihi[0] >> 2 : ihi[0]) - x0u + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
             pitch = (nx + 3) & ~3;
             slice = ny * pitch;
             slice += (slice & 4) ? 0 : 4;
-            fits = !none && pitch <= PX_MAX && (long long)nz * slice <= (long long)CAP;
+            // (PACKED reads the word after a sample's word as well: keep one word of the tile spare)
+            fits = !none && pitch <= PX_MAX && (long long)nz * slice + (PACKED ? 1 : 0) <= (long long)CAP;
             if (fits || none || kk == 1) break;
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
@@ -527,7 +570,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // previous chunk's reads before these writes
             // lane / n for a wave-uniform n <= 64: (lane + 0.5)/n is at least 0.5/n away from an integer, far above the error of
             // v_rcp_f32 (1 ulp; a correctly rounded division costs 12 VALU instructions here, once per chunk)
-            if (ilo[0] >= 0 && ilo[0] + pitch <= (int)g.dim[0]) {
+            const uint32_t *src = PACKED ? g.abricks : g.bricks; // both edge-replicated up to their brick boundaries
+            const uint32_t src_nbx = PACKED ? g.nbxa : g.nbx;
+            if (x0u >= 0 && x0u + pitch <= (PACKED ? (int)(g.nbxa * 4u) : (int)g.dim[0])) {
                 // rows lie inside the volume in x.  Source: the bricked copy; transport: LDS-DMA (global_load_lds_dwordx4),
                 // 16 bytes per lane straight into the tile, no VGPR round trip, no ds_write, every load of the box in
                 // flight at once.  One instruction fills up to 64 consecutive quads of one z slice: lane -> (x quad q,
@@ -536,17 +581,17 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 const int qpr = pitch >> 2;
                 const int rpw = (int)(64.5f * __builtin_amdgcn_rcpf((float)qpr)); // = 64 / qpr for qpr in 1..16 (the half absorbs the 1-ulp rcp)
                 const int eyl = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)qpr)), q = (int)lane - eyl * qpr;
-                const uint32_t bx = ((uint32_t)ilo[0] >> 2) + (uint32_t)q;
-                const size_t zslab = (size_t)g.nbx * g.nby * 128u;   // bytes per brick layer (2 slices)
+                const uint32_t bx = ((uint32_t)x0u >> 2) + (uint32_t)q;
+                const size_t zslab = (size_t)src_nbx * g.nby * 128u;   // bytes per brick layer (2 slices)
                 for (int eb = 0; eb * rpw < ny; ++eb) {
                     const int ey = eb * rpw + eyl;
                     const bool lane_on = eyl < rpw && ey < ny;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                    const uint32_t voff = (((gy >> 2) * g.nbx + bx) * 8u + (gy & 3u)) * 16u;
+                    const uint32_t voff = (((gy >> 2) * src_nbx + bx) * 8u + (gy & 3u)) * 16u;
                     uint32_t *drow = &tile[eb * rpw * pitch];
                     for (int ez = 0; ez < nz; ++ez) {
                         const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz); // uniform
-                        const char *zbase = reinterpret_cast<const char *>(g.bricks) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
+                        const char *zbase = reinterpret_cast<const char *>(src) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
                         if (lane_on)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zbase + voff),
                                                              (__attribute__((address_space(3))) void *)(drow + ez * slice), 16, 0, 0);
@@ -558,7 +603,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
                 const int rpi = (int)(64.5f * __builtin_amdgcn_rcpf((float)pitch));
                 const int er = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)pitch)), ex = (int)lane - er * pitch;
-                const uint32_t gx = (uint32_t)min(max(ilo[0] + ex, 0), mxx);
+                const int tx0 = PACKED ? 4 * (x0u + ex) : x0u + ex; // first texel of this lane's row unit
+                const uint32_t gx = (uint32_t)min(max(tx0, 0), mxx);
                 const bool lane_on = er < rpi && ex < nx;
 #pragma unroll 4
                 for (int row = er; row < rows; row += rpi) {
@@ -568,9 +614,17 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                     const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
                     if (lane_on) {
-                        const uint32_t w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
+                        const uint32_t *vrow = g.vox + ((size_t)gz * g.dim[1] + gy) * g.dim[0];
+                        uint32_t w = vrow[gx];
+                        if (PACKED) { // alpha of texels tx0 .. tx0+3, each clamped to the edge
+                            w >>= 24;
+#pragma unroll
+                            for (int k = 1; k < 4; ++k) w |= (vrow[min(max(tx0 + k, 0), mxx)] >> 24) << (8 * k);
+                            seen |= w ? 0xff000000u : 0u;
+                        } else {
+                            seen |= w;
+                        }
                         tile[ez * slice + ey * pitch + ex] = w;
-                        seen |= w;
                     }
                 }
             }
@@ -606,13 +660,15 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             // lies inside the volume with margin ("interior", the common case) skips p and the test and takes
             // u = dt*(rd*scale) + (ro*scale + bias - box origin) in one FMA per axis.
             const float fpx = (float)pitch, fsl = (float)slice;
-            const float amax = (float)((nz - 2) * slice + (ny - 2) * pitch + (nx - 2)); // word address of the last corner cell
+            // word address of the last corner cell (PACKED: of the last word a sample's texel x can lie in)
+            const float amax = (float)((nz - 2) * slice + (ny - 2) * pitch + (nx - (PACKED ? 1 : 2)));
             auto steps = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
                 float bl[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
-                    bl[a] = (INTERIOR ? __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]) : g.tex_bias[a]) - (float)ilo[a];
+                    bl[a] = (INTERIOR ? __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]) : g.tex_bias[a]) -
+                            (float)(a == 0 ? (PACKED ? 4 * x0u : x0u) : ilo[a]);
                 for (int j = 0; j < kk; ++j) {
                     if (j < n_lane && active) {
                         if (DIAG) ++iters;
@@ -638,15 +694,27 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
-                            const float af = __builtin_fmaf(f2, fsl, __builtin_fmaf(f1, fpx, f0)); // exact: small integers
+                            // (PACKED: the column is the word floor(x / 4); byte x & 3 of it and the byte after)
+                            const float fc = PACKED ? floorf(f0 * 0.25f) : f0;
+                            const float af = __builtin_fmaf(f2, fsl, __builtin_fmaf(f1, fpx, fc)); // exact: small integers
                             const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax);
                             const int a1 = a0 + pitch, a2 = a0 + slice, a3 = a2 + pitch;
-                            uint32_t c[8];
-                            c[0] = tile[a0]; c[1] = tile[a0 + 1];
-                            c[2] = tile[a1]; c[3] = tile[a1 + 1];
-                            c[4] = tile[a2]; c[5] = tile[a2 + 1];
-                            c[6] = tile[a3]; c[7] = tile[a3 + 1];
-                            done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                            if constexpr (PACKED) {
+                                const uint32_t sh = (uint32_t)(int)f0 & 3u;
+                                uint32_t w[4];
+                                w[0] = __builtin_amdgcn_alignbyte(tile[a0 + 1], tile[a0], sh);
+                                w[1] = __builtin_amdgcn_alignbyte(tile[a1 + 1], tile[a1], sh);
+                                w[2] = __builtin_amdgcn_alignbyte(tile[a2 + 1], tile[a2], sh);
+                                w[3] = __builtin_amdgcn_alignbyte(tile[a3 + 1], tile[a3], sh);
+                                done = shade_packed<USE_TF>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                            } else {
+                                uint32_t c[8];
+                                c[0] = tile[a0]; c[1] = tile[a0 + 1];
+                                c[2] = tile[a1]; c[3] = tile[a1 + 1];
+                                c[4] = tile[a2]; c[5] = tile[a2 + 1];
+                                c[6] = tile[a3]; c[7] = tile[a3 + 1];
+                                done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                            }
                         }
                         if (!done) {
                             dt += VRM_STEP_SIZE;
@@ -824,6 +892,34 @@ __global__ void __launch_bounds__(256) build_bricks_kernel(const uint32_t *__res
         w.z = row[min(x + 2u, X - 1u)];
         w.w = row[min(x + 3u, X - 1u)];
         bricks[i] = w;
+    }
+}
+
+// The alpha channel alone, bricked like `bricks` over words of four x-adjacent texels (VrmGridDev::abricks): one
+// 16-byte quad = 16 texels of one (y, z) row, edge-replicated past the volume.
+__global__ void __launch_bounds__(256) build_alpha_bricks_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
+                                                                 uint32_t nbxa, uint32_t nby, size_t n_quads,
+                                                                 u32x4 *__restrict__ abricks)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += stride) {
+        const size_t brick = i >> 3;
+        const uint32_t local = (uint32_t)i & 7u;
+        const size_t bz = brick / ((size_t)nbxa * nby), r = brick - bz * nbxa * nby;
+        const uint32_t by = (uint32_t)(r / nbxa), bx = (uint32_t)(r - (size_t)by * nbxa);
+        const uint32_t y = min(by * 4u + (local & 3u), Y - 1u), z = min((uint32_t)bz * 2u + (local >> 2), Z - 1u);
+        const uint32_t *row = vox + ((size_t)z * Y + y) * X;
+        const uint32_t x = bx * 16u;
+        uint32_t w[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            w[q] = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) w[q] |= (row[min(x + 4u * q + k, X - 1u)] >> 24) << (8u * k);
+        }
+        u32x4 o;
+        o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+        abricks[i] = o;
     }
 }
 
@@ -1012,8 +1108,8 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
     do {                                                                                                       \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                   \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV>), grid, block, 0, stream, p);       \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV>), grid, block, 0, stream, p);           \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, false>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, false>), grid, block, 0, stream, p);     \
     } while (0)
         // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
         // 10 KB is the measured optimum for 256^3 .. 1024^3 volumes (tools/prof_workload.py --all); the others are
@@ -1023,7 +1119,22 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         case 3: VRM_LDS(2304, 8.0f); break;  //  9 KB -> 17 waves/CU
         case 4: VRM_LDS(3072, 9.0f); break;  // 12 KB -> 13 waves/CU
         case 5: VRM_LDS(4096, 16.0f); break; // 16 KB -> 10 waves/CU
-        default: VRM_LDS(2560, 8.0f); break; // 10 KB -> 16 waves/CU (variant 1, the default)
+        default:
+            // 1-channel march (scalar volume or transfer function): staged from the packed alpha bricks -- a quarter of
+            // the bytes and of the tile's x extent, so 12 texels of depth fit where the RGBA tile holds 8.  Measured
+            // against the RGBA source (tools/prof_workload.py --packed 0/1): C4 2.10 -> 1.50 ms/view, C3 with the
+            // transfer function 0.42 -> 0.36, C2 0.136 -> 0.128; smaller tiles (more waves per CU) lose.
+            // VRM_OPT_PACKED_ALPHA = 0 keeps the RGBA source.
+            if constexpr (A) {
+                if (p.grid.abricks != nullptr && p.packed_alpha != 0) {
+                    if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf(12.0f / tps + 0.5f), 2.0f), 64.0f);
+                    if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, 2560, true>), grid, block, 0, stream, p);
+                    else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, 2560, true>), grid, block, 0, stream, p);
+                    break;
+                }
+            }
+            VRM_LDS(2560, 8.0f); // 10 KB -> 16 waves/CU (variant 1, the default)
+            break;
         }
 #undef VRM_LDS
     }
@@ -1037,6 +1148,20 @@ hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], u
     const size_t n_quads = (size_t)nbx * nby * nbz * 8;
     hipLaunchKernelGGL(build_bricks_kernel, dim3(stream_blocks(n_quads)), dim3(256), 0, stream, vox, dim[0], dim[1], dim[2], nbx, nby,
                        n_quads, reinterpret_cast<u32x4 *>(bricks));
+    return hipGetLastError();
+}
+
+size_t vrm_alpha_bricks_bytes(const uint32_t dim[3])
+{
+    return (size_t)((dim[0] + 15) / 16) * ((dim[1] + 3) / 4) * ((dim[2] + 1) / 2) * 128;
+}
+
+hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream)
+{
+    const uint32_t nbxa = (dim[0] + 15) / 16, nby = (dim[1] + 3) / 4, nbz = (dim[2] + 1) / 2;
+    const size_t n_quads = (size_t)nbxa * nby * nbz * 8;
+    hipLaunchKernelGGL(build_alpha_bricks_kernel, dim3(stream_blocks(n_quads)), dim3(256), 0, stream, vox, dim[0], dim[1], dim[2], nbxa,
+                       nby, n_quads, reinterpret_cast<u32x4 *>(abricks));
     return hipGetLastError();
 }
 
