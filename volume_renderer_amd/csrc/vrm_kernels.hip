@@ -561,6 +561,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             }
         }
 
+#ifdef VRM_TIMING_NO_STAGE // timing build: prologue + dt advance only
+        empty = true;
+#endif
         if (fits && !empty) {
             // ---- stage the box: rows along x, clamp-to-edge applied here --------------------------
             const int rows = ny * nz;
@@ -633,6 +636,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             __builtin_amdgcn_wave_barrier();
         }
 
+#ifdef VRM_TIMING_NO_STEPS // timing build: prologue + staging + dt advance, no samples
+        empty = true;
+#endif
         if (empty) {
             // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
             for (int j = 0; j < kk; ++j) {
