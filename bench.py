@@ -37,13 +37,16 @@ def run_c5(a):
     rank, local_rank, world = vd.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearse = os.environ.get("VRM_BENCH_REHEARSE", "0") == "1"   # all ranks on GPU 0, exchange over gloo (see main())
+    gpu = 0 if rehearse else local_rank
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    coll_dev = "cpu" if rehearse else dev
     if world > 1:
-        vd.init_process_group("nccl")
+        vd.init_process_group("gloo" if rehearse else "nccl")
     D, R = a.c5_dim, a.c5_res
     dims = (D, D, 2 * D)
-    rm = vr.RayMarcher(local_rank, R, R)
+    rm = vr.RayMarcher(gpu, R, R)
     rm.set_option(vr.OPT_KERNEL, a.kernel)
     rm.set_option(vr.OPT_SKIP_EMPTY, a.skip_empty)
     slr = sortlast.SortLastRenderer(rm, dims)
@@ -67,7 +70,7 @@ def run_c5(a):
     def step():
         last = None
         for c0 in range(0, len(cams), B):
-            last = slr.render(cams[c0:c0 + B], R, R, dev)
+            last = slr.render(cams[c0:c0 + B], R, R, dev, host_exchange=rehearse)
         return last
 
     n_ref = rm.count_reference_samples(cams, R, R)
@@ -80,7 +83,7 @@ def run_c5(a):
         step()
     torch.cuda.synchronize()
     vd.barrier()
-    elapsed = vd.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = vd.max_over_ranks(time.perf_counter() - t0, coll_dev)
 
     # where the time goes on this rank: march of the partials vs exchange + composite (one more, instrumented, step)
     rm.set_option(vr.OPT_PROFILE, 1)
@@ -111,6 +114,8 @@ def run_c5(a):
                      "avg_launch_ms": round(march_ms, 3), "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B},
         "cpu_baseline": None,
     }
+    if rehearse:
+        out["rehearsal"] = True
     if rank == 0:
         print(json.dumps(out), flush=True)
     rm.close()
@@ -173,14 +178,19 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VRM_BENCH_REHEARSE=1: a logic rehearsal of the N-rank flow on a box with ONE GPU -- every rank renders on GPU 0 and
+    # the collectives run over gloo on host tensors.  The line it prints carries "rehearsal": true and is not a measurement.
+    rehearse = os.environ.get("VRM_BENCH_REHEARSE", "0") == "1"
+    gpu = 0 if rehearse else local_rank
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    coll_dev = "cpu" if rehearse else dev
     if world > 1:
-        vd.init_process_group("nccl")
+        vd.init_process_group("gloo" if rehearse else "nccl")
 
     D, R = a.dim, a.res
     dims = (D, D, D)
-    rm = vr.RayMarcher(local_rank, R, R)
+    rm = vr.RayMarcher(gpu, R, R)
     rm.set_option(vr.OPT_KERNEL, a.kernel)
     rm.set_option(vr.OPT_SKIP_EMPTY, a.skip_empty)
 
@@ -199,7 +209,10 @@ def main():
     vd.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    vd.broadcast_volume(vol, src=0)
+    if rehearse and world > 1:
+        vol = vd.broadcast_volume(vol.cpu(), src=0).to(dev)
+    else:
+        vd.broadcast_volume(vol, src=0)
     torch.cuda.synchronize()
     bcast_ms = (time.time() - t0) * 1e3 if world > 1 else 0.0
     rm.voxel_grid.new(dims)
@@ -253,10 +266,10 @@ def main():
     torch.cuda.synchronize()
     vd.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = vd.max_over_ranks(elapsed, dev)
+    elapsed = vd.max_over_ranks(elapsed, coll_dev)
     kernel_ms, launches = rm.profile_read()
     rm.set_option(vr.OPT_PROFILE, 0)
-    n_ref = vd.sum_over_ranks(n_ref_mine, dev)
+    n_ref = vd.sum_over_ranks(n_ref_mine, coll_dev)
 
     # the same export with skipping off (every reference sample actually taken), one step, for transparency
     no_skip = None
@@ -271,7 +284,7 @@ def main():
         rm.synchronize()
         torch.cuda.synchronize()
         vd.barrier()
-        no_skip = n_views / vd.max_over_ranks(time.perf_counter() - t0, dev)
+        no_skip = n_views / vd.max_over_ranks(time.perf_counter() - t0, coll_dev)
         rm.set_option(vr.OPT_SKIP_EMPTY, 1)
 
     views_per_s = n_views * a.steps / elapsed
@@ -301,8 +314,9 @@ def main():
                 "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
                 "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B}
     # SURVEY.md 8(d) prices the voxels in the INPUT file's format (f32 RGBA = 16 B, f32 scalar = 4 B); the kernel
-    # reads the RGBA8 texels the reference's own texture holds (4 B), so `achieved`/`frac` above use 4 B (the
-    # lower figure). The survey-priced pair is carried beside it so either convention can be checked.
+    # reads the RGBA8 texels the reference's own texture holds (4 B; 1 B for the 1-channel march), so `achieved` and
+    # `frac` above use those (the lower figures). The survey-priced pair is carried beside them so either convention
+    # can be checked.
     in_bytes = 16 if a.volume == "rgba" else 4
     b_alg_survey = D * D * D * in_bytes + R * R * 4
     ach_survey = achieved * b_alg_survey / b_alg_view
@@ -351,6 +365,8 @@ def main():
                       f"({cpu_samples} samples in {cpu_s:.2f} s, OpenMP over image rows)",
             "gsamples_per_s": round(cpu_samples / cpu_s / 1e9, 5),
         }
+    if rehearse:
+        out["rehearsal"] = True   # N ranks on one GPU over gloo: logic check only, never a measurement
     if rank == 0:
         print(json.dumps(out), flush=True)
     for bank in banks:

@@ -125,3 +125,20 @@ def test_sort_last_equals_unpartitioned_render(rm1, vr, orc, n_slabs):
         assert np.abs(out8.cpu().numpy().astype(int) - ref8.astype(int)).max() <= 1
         assert full[i].max() > 0.05
     img.close()
+
+
+@pytest.mark.parametrize("ranks,scalar", [(2, "1"), (3, "0")])
+def test_sortlast_end_to_end_ranks_on_one_gpu(ranks, scalar):
+    """tools/rehearse_sortlast.py: `ranks` processes (one SortLastRenderer each) share GPU 0, march their slabs with the
+    HIP kernels, exchange row bands over gloo, composite on the GPU; rank 0 compares with the unpartitioned render."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REHEARSE_SCALAR=scalar, MASTER_ADDR="127.0.0.1")
+    port = 29520 + ranks
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "rehearse_sortlast.py")],
+                       env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "-> OK" in r.stdout

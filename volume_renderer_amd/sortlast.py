@@ -135,15 +135,20 @@ class SortLastRenderer:
             raise ValueError(f"expected slices [{self.s0},{self.s1}) as {(self.s1 - self.s0, self.dims[1], self.dims[0])}, got {v.shape}")
         self.rm.voxel_grid.upload_scalar(v.reshape(-1), (self.dims[0], self.dims[1], self.s1 - self.s0), 1)
 
-    def render(self, camera_uniforms, width, height, device):
+    def render(self, camera_uniforms, width, height, device, host_exchange=False):
         """Render the views cooperatively.  Returns (band_rgba8, row0, rows): this rank's row band of every view as a
-        torch uint8 tensor (n, rows, W, 4) on `device`."""
+        torch uint8 tensor (n, rows, W, 4) on `device`.  host_exchange: route the all-to-all through host tensors (a
+        gloo process group, e.g. several ranks rehearsing on one GPU); the default hands device tensors to RCCL."""
         import torch
         n = len(camera_uniforms)
         partial = torch.empty((n, height, width, 4), dtype=torch.float32, device=device)
         self.rm.draw_partial(camera_uniforms, width, height, partial.data_ptr())
         self.rm.synchronize()                       # the library's stream -> visible to torch / RCCL
-        stack, row0, rows = exchange_bands(partial, self.group)
+        if host_exchange:
+            stack, row0, rows = exchange_bands(partial.cpu(), self.group)
+            stack = stack.to(device)
+        else:
+            stack, row0, rows = exchange_bands(partial, self.group)
         out = torch.empty((n, rows, width, 4), dtype=torch.uint8, device=device)
         if rows > 0:
             per_view = stack.permute(1, 0, 2, 3, 4).contiguous()          # (n, G, rows, W, 4)
