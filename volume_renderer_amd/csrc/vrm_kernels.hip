@@ -373,6 +373,45 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// n iterations of `dt += 0.001f; if (dt >= t_max) stop` (wgsl:181-186) with no sample in between, result-identical to
+// taking them one by one.  While dt stays inside one binade and h = 0.001f is added to a multiple of the binade's ulp u,
+// the sum rounds the same way every time: dt -> dt + inc with one fixed multiple inc of u (the discarded fraction of h
+// is the same at every step; a fraction of exactly u/2, where round-to-even would alternate, shows as two consecutive
+// increments that differ and is sent to the slow path).  dt + j*inc is then exactly representable, so j steps are ONE
+// fused multiply-add, and the step that first reaches t_max is found by comparing such exact values.  Steps that cross
+// into the next binade, tiny or negative dt go one at a time.  Used where a chunk has nothing to sample (empty-space
+// skipping) and to bring a ray up to its rank's slab (sort-last): the iteration lattice is the oracle's, bit for bit.
+__device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_max, int n)
+{
+    while (n > 0 && active) {
+        const float d1 = dt + VRM_STEP_SIZE;
+        const float inc = d1 - dt; // exact (Sterbenz)
+        int k = 0;                 // steps from here that stay regular: the exact sum dt_j + h stays below the binade's end
+        if (dt >= 0x1p-8f && inc > 0.0f && (d1 + VRM_STEP_SIZE) - d1 == inc) {
+            const float end = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, dt) & 0x7f800000u) + 0x00800000u);
+            // (j-1)*inc < end - h - dt for every regular step j; v_rcp_f32 and the roundings are covered by the 0.01 + floor
+            k = (int)fminf(floorf(((end - VRM_STEP_SIZE) - dt) * __builtin_amdgcn_rcpf(inc) - 0.01f), (float)n);
+        }
+        if (k < 2) { // one plain step
+            dt = d1;
+            active = !(dt >= t_max);
+            --n;
+            continue;
+        }
+        // c = the first j >= 1 with dt + j*inc >= t_max, searched in [1, k+1]; the estimate is corrected with exact values
+        float c = fminf(fmaxf(ceilf((t_max - dt) * __builtin_amdgcn_rcpf(inc)), 1.0f), (float)(k + 1));
+        while (c > 1.0f && __builtin_fmaf(c - 1.0f, inc, dt) >= t_max) c -= 1.0f;
+        while (c <= (float)k && __builtin_fmaf(c, inc, dt) < t_max) c += 1.0f;
+        if (c <= (float)k) { // the ray ends inside this run
+            dt = __builtin_fmaf(c, inc, dt);
+            active = false;
+            return;
+        }
+        dt = __builtin_fmaf((float)k, inc, dt);
+        n -= k;
+    }
+}
+
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED>
 __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 {
@@ -477,12 +516,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             else if (dz < 0.0f && uz >= hi1) ff = (hi1 - uz) / dz;
             const int nff = uni((int)fminf(wave_min(active ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
             if (nff > 0) {
-                for (int j = 0; j < nff; ++j) {
-                    if (active) {
-                        dt += VRM_STEP_SIZE;
-                        active = !(dt >= ray.t_max);
-                    }
-                }
+                advance_exact(dt, active, ray.t_max, nff);
                 steps_left -= nff;
                 active = active && steps_left > 0;
                 continue;
@@ -641,6 +675,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #endif
         if (empty) {
             // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
+            if (!DIAG) advance_exact(dt, active, ray.t_max, n_lane); // (the diagnostics build counts in-box samples per step)
+            else
             for (int j = 0; j < kk; ++j) {
                 if (j < n_lane && active) {
                     if (DIAG) {
