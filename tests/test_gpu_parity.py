@@ -6,6 +6,7 @@ to 1e-4 and the ray geometry (direction, t_min, t_max, iteration count, in-box s
 to be BIT-EXACT, because it drives the discontinuous decisions of the shader."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libvrm.so initialises HIP: the library then shares torch's runtime, see bench.py)
 
 from conftest import image_metrics, sphere_cam
 from volume_renderer_amd import synth
@@ -319,3 +320,38 @@ def test_one_channel_staging_sources_agree(rm, vr, orc):
     assert np.abs(out[0]["f32"] - out[1]["f32"]).max() < 1e-5
     assert np.abs(out[0]["rgba8"].astype(int) - out[1]["rgba8"].astype(int)).max() <= 1
     assert out[0]["rgba8"][..., 3].max() > 50
+
+
+def test_production_f32_accumulators_equal_diagnostics_build(rm, vr, orc):
+    """The production kernels cross empty chunks with advance_exact (n steps of the running f32 dt sum in O(1) per
+    binade); the diagnostics build, which the oracle comparisons above read, takes them one by one.  The f32
+    accumulators of the production kernel (vrm_draw_partial) must be BIT-identical: one step off the lattice anywhere
+    moves every later sample.  Long empty runs in front of the data, t crossing the binades at 2, 4 and 64..128,
+    negative t inside the volume, tiny t."""
+    W, H = 88, 72
+    far = np.zeros((48, 40, 56, 4), np.uint8)                      # (Z, Y, X, 4): data only in the last z slices and a corner
+    far[40:, :, :, :] = synth.random_rgba8((56, 40, 8), 3)
+    far[:6, :5, :7, :] = 200
+    cases = [(synth.quantize_rgba8(synth.blobs_rgba_f32((64, 64, 64))), 8.0, False),
+             (np.repeat(synth.blobs_scalar_u8((72, 48, 40))[..., None], 4, 3), 15.0, True),
+             (far, 30.0, False)]
+    cams = [sphere_cam(orc, 1, 3, radius=2.5, aspect=W / H), sphere_cam(orc, 6, 5, radius=1.2, aspect=W / H),
+            sphere_cam(orc, 3, 2, radius=4.5, aspect=W / H), sphere_cam(orc, 0, 4, radius=100.0, aspect=W / H),
+            sphere_cam(orc, 5, 6, radius=9.0, aspect=W / H),
+            orc.camera_uniform((0.1, 0.05, -0.2), target=(0.4, 0.3, 0.5), aspect=W / H),
+            orc.camera_uniform((0.0, 0.0, 0.0), target=(-0.3, 0.9, 0.2), aspect=W / H)]
+    nonzero = 0
+    for vox, att, tf in cases:
+        configure(rm, vox, att, tf)
+        for skip in (1, 0):
+            rm.set_option(vr.OPT_SKIP_EMPTY, skip)
+            part = torch.empty((len(cams), H, W, 4), dtype=torch.float32, device="cuda")
+            rm.draw_partial([vr.uniform_from_array(c) for c in cams], W, H, part.data_ptr())
+            rm.synchronize()
+            prod = part.cpu().numpy()
+            for i, c in enumerate(cams):
+                ref = draw(rm, vr, c, W, H, diag=True)["f32"]
+                assert np.array_equal(prod[i].view(np.uint32), ref.view(np.uint32)), (i, skip, float(np.abs(prod[i] - ref).max()))
+                nonzero += int(ref[..., 3].max() > 0.05)
+    rm.set_option(vr.OPT_SKIP_EMPTY, 1)
+    assert nonzero >= 30
