@@ -270,3 +270,31 @@ def test_netcdf_load_and_write(rm1, vr, orc, tmp_path):
     assert np.array_equal(g.download_rgba8(), vox)
     with pytest.raises(vr.VrmError):
         rm1.load_netcdf(os.path.join(tmp_path, "missing.nc"))
+
+
+def test_resize_that_cannot_be_allocated_leaves_a_usable_context(vr, orc):
+    """A grid that does not fit the GPU: the call fails with the HIP error, the context falls back to the start-up
+    3x3x3 grid (not to dangling or null buffers), draws keep working and a later resize succeeds."""
+    from volume_renderer_amd import _ffi
+    r = vr.RayMarcher(0, 32, 32)
+    try:
+        r.voxel_grid.new((20, 20, 20))
+        L = _ffi.lib()
+        rc = L.vrm_grid_resize(r._h, 8192, 8192, 8192)            # 2 TiB of RGBA8 alone
+        assert rc == _ffi.VRM_ERR_HIP
+        msg = L.vrm_last_error().decode()
+        assert "8192 x 8192 x 8192" in msg and "3 x 3 x 3" in msg
+        u = r.voxel_grid.uniform()
+        assert list(u.dimensions)[:3] == [3, 3, 3]
+        cam = sphere_cam(orc, 1, 3)
+        img = vr.Screenshotter(r, 32, 32)
+        r.draw(vr.uniform_from_array(cam), img)
+        vox = np.zeros((3, 3, 3, 4), np.uint8)
+        vox[..., 3] = 255
+        assert image_metrics(img.read(), orc.render(vox, cam, 32, 32)["rgba8"])["max"] <= 1
+        img.close()
+        assert L.vrm_grid_resize(r._h, 0, 4, 4) == _ffi.VRM_ERR_INVALID
+        _ffi.check(L.vrm_grid_resize(r._h, 12, 12, 12))
+        assert list(r.voxel_grid.uniform().dimensions)[:3] == [12, 12, 12]
+    finally:
+        r.close()

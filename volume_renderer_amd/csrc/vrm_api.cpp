@@ -59,25 +59,26 @@ static int bind(vrm_ctx *ctx)
     return vrm_check_hip(hipSetDevice(ctx->device), "hipSetDevice");
 }
 
-static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
+static void grid_free(vrm_ctx *ctx)
 {
-    REQUIRE(x > 0 && y > 0 && z > 0, "grid dimensions must be non-zero (got %u x %u x %u)", x, y, z);
-    const size_t words = (size_t)x * y * z;
-    REQUIRE(words < ((size_t)1 << 40), "grid too large");
-    // draws in flight still read the old volume: they are on ctx->stream, so order the free behind them
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (ctx->vox) HIP_TRY(hipFree(ctx->vox));
+    if (ctx->vox) (void)hipFree(ctx->vox);
+    if (ctx->occ) (void)hipFree(ctx->occ);
+    if (ctx->bricks) (void)hipFree(ctx->bricks);
+    if (ctx->abricks) (void)hipFree(ctx->abricks);
     ctx->vox = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
-    if (ctx->occ) HIP_TRY(hipFree(ctx->occ));
     ctx->occ = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 3) / 4)));
-    if (ctx->bricks) HIP_TRY(hipFree(ctx->bricks));
     ctx->bricks = nullptr;
-    HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
-    if (ctx->abricks) HIP_TRY(hipFree(ctx->abricks));
     ctx->abricks = nullptr;
+    ctx->vox_words = 0;
+}
+
+static int grid_alloc_buffers(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
+{
+    const size_t words = (size_t)x * y * z;
     const uint32_t xyz[3] = {x, y, z};
+    HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
+    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 3) / 4)));
+    HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
     HIP_TRY(hipMalloc((void **)&ctx->abricks, vrm_alpha_bricks_bytes(xyz)));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
@@ -86,6 +87,31 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     ctx->slab_z0 = 0;
     ctx->slab_z1 = z;
     return VRM_OK;
+}
+
+static int grid_reset_contents(vrm_ctx *ctx);
+
+// The old volume is released BEFORE the new one is allocated (a 64 GiB slab and its successor need not fit side by
+// side).  If the new one cannot be allocated the context falls back to the start-up grid (3x3x3 default voxels,
+// ray_marcher/mod.rs:29) so that it stays usable, and the call reports the allocation failure.
+static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
+{
+    REQUIRE(x > 0 && y > 0 && z > 0, "grid dimensions must be non-zero (got %u x %u x %u)", x, y, z);
+    REQUIRE((size_t)x * y * z < ((size_t)1 << 40), "grid too large");
+    // draws in flight still read the old volume: they are on ctx->stream, so order the free behind them
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    grid_free(ctx);
+    int rc = grid_alloc_buffers(ctx, x, y, z);
+    if (rc == VRM_OK) return rc;
+    char why[512];
+    snprintf(why, sizeof why, "%s", vrm_last_error());
+    (void)hipGetLastError(); // clear the sticky allocation error
+    grid_free(ctx);
+    if (grid_alloc_buffers(ctx, 3, 3, 3) == VRM_OK && grid_reset_contents(ctx) == VRM_OK)
+        vrm_set_error("cannot allocate a %u x %u x %u grid (%s); the context now holds the 3 x 3 x 3 start-up grid", x, y, z, why);
+    else
+        grid_free(ctx);
+    return rc;
 }
 
 static int grid_reset_contents(vrm_ctx *ctx)
@@ -535,6 +561,10 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
     if (rc) return rc;
     REQUIRE(cameras != nullptr && targets != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
+    if (!ctx->vox) {
+        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
+        return VRM_ERR_STATE;
+    }
     const uint32_t w = targets[0] ? targets[0]->width : 0, h = targets[0] ? targets[0]->height : 0;
     for (uint32_t i = 0; i < n; ++i) {
         REQUIRE(targets[i] != nullptr && targets[i]->ctx == ctx, "target %u is null or belongs to another context", i);
@@ -614,6 +644,10 @@ extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras,
 {
     int rc = bind(ctx);
     if (rc) return rc;
+    if (!ctx->vox) {
+        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
+        return VRM_ERR_STATE;
+    }
     REQUIRE(cameras != nullptr && rgba_f32_device != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
@@ -662,6 +696,10 @@ extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_unifor
 {
     int rc = bind(ctx);
     if (rc) return rc;
+    if (!ctx->vox) {
+        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
+        return VRM_ERR_STATE;
+    }
     REQUIRE(cameras != nullptr && out_total != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
