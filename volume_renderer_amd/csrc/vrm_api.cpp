@@ -98,6 +98,8 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
 {
     REQUIRE(x > 0 && y > 0 && z > 0, "grid dimensions must be non-zero (got %u x %u x %u)", x, y, z);
     REQUIRE((size_t)x * y * z < ((size_t)1 << 40), "grid too large");
+    // the staging offsets inside one brick layer are 32-bit: 8 bytes per texel of a z slice must stay below 4 GiB
+    REQUIRE((size_t)x * y <= ((size_t)1 << 28), "a z slice of %u x %u texels exceeds 2^28 (16384 x 16384)", x, y);
     // draws in flight still read the old volume: they are on ctx->stream, so order the free behind them
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     grid_free(ctx);
