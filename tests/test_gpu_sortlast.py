@@ -139,6 +139,6 @@ def test_sortlast_end_to_end_ranks_on_one_gpu(ranks, scalar):
     port = 29520 + ranks
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "rehearse_sortlast.py")],
-                       env=env, capture_output=True, text=True, timeout=110)
+                       env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "-> OK" in r.stdout
