@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=80)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--slab-cases", type=int, default=30, help="sort-last cases: production slab partials vs the oracle's")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     rm = vr.RayMarcher(0, 64, 64)
@@ -91,8 +92,64 @@ def main():
         else:
             if case % 10 == 0:
                 print("ok  ", desc, flush=True)
+    # ---- sort-last: production-kernel partials of random z slabs (fast-forward to the slab, stop past it) against
+    # the oracle's slab partials, and their "over" against the oracle's unpartitioned accumulators ----------------
+    from volume_renderer_amd import sortlast
+    for k in (vr.OPT_KERNEL, vr.OPT_SKIP_EMPTY, vr.OPT_PACKED_ALPHA):
+        rm.set_option(k, 1)
+    rm.set_option(vr.OPT_CHUNK_STEPS, 0)
+    for case in range(a.slab_cases):
+        dims = (int(rng.integers(4, 40)), int(rng.integers(4, 40)), int(rng.integers(6, 70)))
+        X, Y, Z = dims
+        scalar = bool(rng.random() < 0.5)
+        if scalar:
+            sc = rng.integers(0, 256, (Z, Y, X), dtype=np.uint8)
+            sc[rng.random((Z, Y, X)) < 0.6] = 0
+            vox = np.repeat(sc[..., None], 4, 3)
+        else:
+            vox = synth.random_rgba8(dims, int(rng.integers(1 << 30)))
+            vox[rng.random((Z, Y, X)) < 0.5] = 0
+        W, H = int(rng.integers(8, 90)), int(rng.integers(8, 70))
+        att = float(rng.choice([1.0, 10.0, 60.0]))
+        G = int(rng.integers(2, min(6, Z // 2) + 1))
+        if rng.random() < 0.3:
+            pos = tuple(float(v) for v in rng.uniform(-0.4, 0.4, 3) * np.array(dims) / min(dims))
+            tgt = tuple(float(v) for v in rng.uniform(-1.0, 1.0, 3))
+        else:
+            pos = orc.sphere_position(int(rng.integers(0, 8)), int(rng.integers(1, 8)), 8, 8, float(rng.uniform(1.2, 6.0)) * max(dims) / min(dims))
+            tgt = (0.0, 0.0, 0.0)
+        if abs(np.cross(np.subtract(tgt, pos), (0, 1, 0))).max() < 1e-3:
+            continue
+        cam = orc.camera_uniform(pos, target=tgt, aspect=W / H)
+        desc = f"slab case {case}: dims {dims} {'scalar' if scalar else 'rgba'} image {W}x{H} att {att} G {G} cam {np.round(pos, 3).tolist()}"
+        try:
+            parts = []
+            for z0, z1 in sortlast.slab_ranges(Z, G):
+                s0, s1 = rm.voxel_grid.new_slab(dims, z0, z1)
+                if scalar:
+                    rm.voxel_grid.upload_scalar(np.ascontiguousarray(vox[s0:s1, :, :, 0]).reshape(-1), (X, Y, s1 - s0), 1)
+                else:
+                    rm.voxel_grid.upload_rgba8(vox[s0:s1])
+                rm.voxel_grid.attenuation = att
+                rm.voxel_grid.update_voxel_grid_buffer()
+                t = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda:0")
+                rm.draw_partial([vr.uniform_from_array(cam)], W, H, t.data_ptr())
+                rm.synchronize()
+                got = t.cpu().numpy()[0]
+                want = orc.render_slab(vox, cam, W, H, z0, z1, attenuation=att)
+                assert np.abs(got - want).max() <= 1e-4, f"slab [{z0},{z1}) partial differs by {np.abs(got - want).max():g}"
+                parts.append(got)
+            full = orc.render(vox, cam, W, H, attenuation=att)["f32"]
+            comp = sortlast.composite_numpy(np.stack(parts), sortlast.ascending_mask(cam, W, H))
+            assert np.abs(comp - full).max() <= 1e-4, f"composite differs by {np.abs(comp - full).max():g}"
+        except AssertionError as e:
+            fails += 1
+            print("FAIL", desc, "::", str(e)[:300], flush=True)
+        else:
+            if case % 10 == 0:
+                print("ok  ", desc, flush=True)
     rm.close()
-    print(f"fuzz: {a.cases} cases, {fails} failures")
+    print(f"fuzz: {a.cases} cases + {a.slab_cases} slab cases, {fails} failures")
     sys.exit(1 if fails else 0)
 
 
