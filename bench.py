@@ -287,6 +287,15 @@ def main():
         no_skip = n_views / vd.max_over_ranks(time.perf_counter() - t0, coll_dev)
         rm.set_option(vr.OPT_SKIP_EMPTY, 1)
 
+    # samples actually filtered (N_exec): one pass of this rank's views through the diagnostics build
+    rm.set_option(vr.OPT_DIAGNOSTICS, 1)
+    n_exec_mine = 0
+    for cam_u in my_cams:
+        rm.draw(cam_u, banks[0][0])
+        n_exec_mine += int(banks[0][0].executed_samples().sum(dtype=np.uint64))
+    rm.set_option(vr.OPT_DIAGNOSTICS, 0)
+    n_exec = vd.sum_over_ranks(n_exec_mine, coll_dev)
+
     views_per_s = n_views * a.steps / elapsed
     gsamples = n_ref * a.steps / elapsed / 1e9
 
@@ -334,6 +343,7 @@ def main():
                    "volume": [D, D, D], "image": [R, R], "views": n_views, "parallelism": f"view-partitioned x{world}",
                    "kernel_variant": a.kernel, "skip_empty": a.skip_empty},
         "gsamples_per_s": round(gsamples, 3), "reference_samples_per_step": int(n_ref),
+        "executed_samples_per_step": int(n_exec),
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
         "volume_broadcast_ms": round(bcast_ms, 2), "roofline": roofline,
         "views_per_s_no_skip": None if no_skip is None else round(no_skip, 3),

@@ -268,6 +268,10 @@ VRM_API int vrm_profile_read(vrm_ctx *ctx, double *kernel_ms, uint64_t *launches
 /* With VRM_OPT_DIAGNOSTICS on at draw time: premultiplied f32 RGBA (w*h*4 floats) and per-ray loop
  * iteration counts (w*h u32) of the last draw into `image`; either pointer may be NULL. */
 VRM_API int vrm_image_read_diagnostics(vrm_image *image, float *rgba_f32, uint32_t *iterations);
+/* Same switch: per ray, the number of samples that were actually filtered and blended in the last draw (w*h u32):
+ * the in-box count minus the samples in chunks the empty-space skipping passed over (N_exec of SURVEY.md 8d; the
+ * iteration count above is the reference-equivalent N_ref and does not depend on skipping). */
+VRM_API int vrm_image_read_sample_counts(vrm_image *image, uint32_t *executed);
 /* Same switch: 8 floats per pixel -- ray direction xyz, t_min, t_max, number of samples that passed the
  * in-box test (wgsl:218-223), hit flag (wgsl:131), 0 -- so tests can check the geometry bit for bit. */
 VRM_API int vrm_image_read_ray_diagnostics(vrm_image *image, float *geom8);

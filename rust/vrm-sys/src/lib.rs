@@ -95,6 +95,7 @@ extern "C" {
     pub fn vrm_get_option(ctx: *mut vrm_ctx, option: c_int, value: *mut i64) -> c_int;
     pub fn vrm_profile_read(ctx: *mut vrm_ctx, kernel_ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
     pub fn vrm_image_read_diagnostics(image: *mut vrm_image, rgba_f32: *mut f32, iterations: *mut u32) -> c_int;
+    pub fn vrm_image_read_sample_counts(image: *mut vrm_image, executed: *mut u32) -> c_int;
     pub fn vrm_image_read_ray_diagnostics(image: *mut vrm_image, geom8: *mut f32) -> c_int;
     pub fn vrm_count_reference_samples(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, width: u32, height: u32,
                                        out_total: *mut u64) -> c_int;

@@ -355,3 +355,28 @@ def test_production_f32_accumulators_equal_diagnostics_build(rm, vr, orc):
                 nonzero += int(ref[..., 3].max() > 0.05)
     rm.set_option(vr.OPT_SKIP_EMPTY, 1)
     assert nonzero >= 30
+
+
+def test_executed_sample_counts(rm, vr, orc):
+    """N_exec (vrm_image_read_sample_counts): with skipping off every in-box sample is filtered; with skipping on only
+    those in chunks that were not passed over -- fewer on a sparse volume, never more, and the iteration lattice (N_ref)
+    does not move."""
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((64, 64, 64)))
+    configure(rm, vox, 3.0, False)
+    cam = vr.uniform_from_array(sphere_cam(orc, 2, 3))
+    rm.set_option(vr.OPT_DIAGNOSTICS, 1)
+    img = vr.Screenshotter(rm, 96, 96)
+    res = {}
+    for skip in (0, 1):
+        rm.set_option(vr.OPT_SKIP_EMPTY, skip)
+        rm.draw(cam, img)
+        res[skip] = (img.executed_samples().astype(np.int64), img.ray_diagnostics()[..., 5].astype(np.int64), img.diagnostics()[1].astype(np.int64))
+    rm.set_option(vr.OPT_SKIP_EMPTY, 1)
+    rm.set_option(vr.OPT_DIAGNOSTICS, 0)
+    img.close()
+    ex0, in0, it0 = res[0]
+    ex1, in1, it1 = res[1]
+    assert np.array_equal(ex0, in0) and np.array_equal(in0, in1) and np.array_equal(it0, it1)
+    assert (ex1 <= in1).all() and it0.max() < 5001
+    if rm.get_option(vr.OPT_KERNEL) != 0:          # the global-gather baseline does not skip
+        assert ex1.sum() < 0.9 * in1.sum()

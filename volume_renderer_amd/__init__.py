@@ -248,6 +248,12 @@ class Screenshotter:
         _ffi.check(_ffi.lib().vrm_image_read_diagnostics(self._h, _fp(rgba), it.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         return rgba, it
 
+    def executed_samples(self):
+        """(H, W) u32: samples actually filtered per ray in the last draw with OPT_DIAGNOSTICS on (N_exec)."""
+        n = np.zeros((self.height, self.width), dtype=np.uint32)
+        _ffi.check(_ffi.lib().vrm_image_read_sample_counts(self._h, n.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        return n
+
     def ray_diagnostics(self):
         """(H, W, 8) f32: rd.xyz, t_min, t_max, n_inside, hit, 0."""
         g = np.zeros((self.height, self.width, 8), dtype=np.float32)
@@ -313,6 +319,11 @@ class RayMarcher:
 
     def set_option(self, option, value):
         _ffi.check(_ffi.lib().vrm_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = ctypes.c_int64()
+        _ffi.check(_ffi.lib().vrm_get_option(self._h, int(option), ctypes.byref(v)))
+        return v.value
 
     def profile_read(self, reset=True):
         ms = ctypes.c_double()

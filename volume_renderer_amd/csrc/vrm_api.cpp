@@ -501,6 +501,25 @@ extern "C" int vrm_image_read_diagnostics(vrm_image *img, float *rgba_f32, uint3
     if (rgba_f32) HIP_TRY(hipMemcpyAsync(rgba_f32, img->diag_rgba, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (iterations) HIP_TRY(hipMemcpyAsync(iterations, img->diag_iters, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (iterations)
+        for (size_t i = 0; i < n; ++i) iterations[i] &= 0xFFFFu; // the high half holds the executed-sample count
+    return VRM_OK;
+}
+
+extern "C" int vrm_image_read_sample_counts(vrm_image *img, uint32_t *executed)
+{
+    REQUIRE(img != nullptr && executed != nullptr, "null argument");
+    int rc = bind(img->ctx);
+    if (rc) return rc;
+    if (!img->diag_iters) {
+        vrm_set_error("no diagnostics: set VRM_OPT_DIAGNOSTICS before drawing into this image");
+        return VRM_ERR_STATE;
+    }
+    vrm_ctx *ctx = img->ctx;
+    const size_t n = (size_t)img->width * img->height;
+    HIP_TRY(hipMemcpyAsync(executed, img->diag_iters, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) executed[i] >>= 16;
     return VRM_OK;
 }
 

@@ -224,7 +224,7 @@ __device__ __forceinline__ void finish_colour(Accum &acc)
 
 template <bool DIAG>
 __device__ __forceinline__ void store_pixel(const VrmViewDesc &v, const VrmMarchParams &P, uint32_t px, uint32_t py,
-                                            const Accum &acc, const Ray &ray, uint32_t iters, uint32_t n_inside)
+                                            const Accum &acc, const Ray &ray, uint32_t iters, uint32_t n_inside, uint32_t n_exec)
 {
     const uint32_t packed = unorm8(acc.cr) | (unorm8(acc.cg) << 8) | (unorm8(acc.cb) << 16) | (unorm8(acc.alpha) << 24);
     if (v.out) v.out[(size_t)py * P.pitch_px + px] = packed;
@@ -233,7 +233,9 @@ __device__ __forceinline__ void store_pixel(const VrmViewDesc &v, const VrmMarch
     if (DIAG) {
         const size_t o = (size_t)py * P.width + px;
         if (v.diag_rgba) reinterpret_cast<float4 *>(v.diag_rgba)[o] = make_float4(acc.cr, acc.cg, acc.cb, acc.alpha);
-        if (v.diag_iters) v.diag_iters[o] = iters;
+        // low half: loop iterations (<= 5000); high half: samples actually filtered (N_exec) -- fewer than the
+        // in-box count when empty chunks were skipped
+        if (v.diag_iters) v.diag_iters[o] = iters | (n_exec << 16);
         if (v.diag_geom) {
             float4 *gq = reinterpret_cast<float4 *>(v.diag_geom) + 2 * o;
             gq[0] = make_float4(ray.rd[0], ray.rd[1], ray.rd[2], ray.hit ? ray.t_min : 0.0f);
@@ -304,7 +306,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
         }
         finish_colour<ALPHA_ONLY, USE_TF>(acc);
     }
-    store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
+    store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside, n_inside);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     const Ray ray = setup_ray(v, g, in_image ? px : 0u, in_image ? py : 0u, P.width, P.height);
 
     Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t iters = 0, n_inside = 0;
+    uint32_t iters = 0, n_inside = 0, n_exec = 0;
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
@@ -732,7 +734,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                         }
                         bool done = false;
                         if (inside) {
-                            if (DIAG) ++n_inside;
+                            if (DIAG) { ++n_inside; ++n_exec; }
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
@@ -780,7 +782,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                                         (p1 < g.box_max[1]) & (p2 < g.in_max_z);
                     bool done = false;
                     if (inside) {
-                        if (DIAG) ++n_inside;
+                        if (DIAG) { ++n_inside; ++n_exec; }
                         const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
                         const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
                         const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
@@ -801,7 +803,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         active = active && steps_left > 0;
     }
     finish_colour<ALPHA_ONLY, USE_TF>(acc);
-    if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside);
+    if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside, n_exec);
 }
 
 // ---------------------------------------------------------------------------------------------
