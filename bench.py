@@ -13,6 +13,8 @@ as volume_broadcast_ms).  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,6 +22,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks as a CHILD
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` (one process per GPU,
+    RCCL between them), pass its output through and return its exit code.  Called before torch is imported or
+    anything touches the GPU; the current process is never replaced."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)               # rank 0's ONE line
+    return proc.returncode if proc.returncode != 0 or json_lines else 1
+
+
+def launcher_selftest(a):
+    """VRM_BENCH_LAUNCH_TEST=1 (tests/test_bench_launcher_cpu.py): the rank plumbing of this file without a GPU --
+    gloo rendezvous, world-size check, barrier, max/sum over ranks, rank 0 prints one line."""
+    from volume_renderer_amd import distributed as vd
+    rank, _, world = vd.env_rank()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        import torch.distributed as dist
+        vd.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus
+    vd.barrier()
+    t = vd.max_over_ranks(1.0 + rank)
+    n = vd.sum_over_ranks(len(vd.partition_views(256, rank, world)))
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "max_time": t, "views": int(n), "steps": a.steps,
+                          "warmup": a.warmup}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_c5(a):
@@ -153,6 +202,10 @@ def main():
     ap.add_argument("--volume", default=None, choices=["rgba", "scalar"],
                     help="rgba: f32 color(c,z,y,x) NetCDF-style; scalar: DAT-style density replicated to r=g=b=a")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if os.environ.get("VRM_BENCH_LAUNCH_TEST", "0") == "1":
+        return launcher_selftest(a)
     presets = {"C2": dict(dim=256, res=512, xdiv=8, ydiv=9, volume="scalar"),     # 256^3 u8 DAT, 64 views, 512^2
                "C3": dict(dim=512, res=1024, xdiv=16, ydiv=17, volume="rgba"),    # 512^3 f32 RGBA, 256 views, 1024^2
                "C4": dict(dim=1024, res=2048, xdiv=16, ydiv=9, volume="scalar")}  # 1024^3 f32 scalar, 128 views, 2048^2
@@ -174,8 +227,9 @@ def main():
     from volume_renderer_amd import synth
 
     rank, local_rank, world = vd.env_rank()
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` or as "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-marching path has no CPU fallback")
     # VRM_BENCH_REHEARSE=1: a logic rehearsal of the N-rank flow on a box with ONE GPU -- every rank renders on GPU 0 and
@@ -187,6 +241,8 @@ def main():
     coll_dev = "cpu" if rehearse else dev
     if world > 1:
         vd.init_process_group("gloo" if rehearse else "nccl")
+        import torch.distributed as dist
+        assert dist.get_world_size() == a.gpus
 
     D, R = a.dim, a.res
     dims = (D, D, D)
@@ -238,17 +294,19 @@ def main():
     B = max(1, min(a.batch, len(my_cams)))
     banks = [[vr.Screenshotter(rm, R, R) for _ in range(B)] for _ in range(2)]
 
+    which = [0]                      # the banks alternate across steps too: with one launch per step (8 ranks x 32 views)
+                                     # the read-back of step k overlaps the march of step k+1
+
     def step():
-        which = 0
         for c0 in range(0, len(my_cams), B):
             chunk = my_cams[c0:c0 + B]
-            imgs = banks[which][:len(chunk)]
+            imgs = banks[which[0]][:len(chunk)]
             for im in imgs:          # this bank's previous read-back must have landed before it is redrawn
                 im.wait()
             rm.draw_batch(chunk, imgs)
             for im in imgs:
                 im.screenshot()      # async device->host copy behind the draw
-            which ^= 1
+            which[0] ^= 1
 
     n_ref_mine = rm.count_reference_samples(my_cams, R, R) if my_cams else 0
 
@@ -345,7 +403,7 @@ def main():
         "gsamples_per_s": round(gsamples, 3), "reference_samples_per_step": int(n_ref),
         "executed_samples_per_step": int(n_exec),
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
-        "volume_broadcast_ms": round(bcast_ms, 2), "roofline": roofline,
+        "volume_broadcast_ms": round(bcast_ms, 2), "rccl_ranks": 0 if (rehearse or world == 1) else world, "roofline": roofline,
         "views_per_s_no_skip": None if no_skip is None else round(no_skip, 3),
     }
 

@@ -62,6 +62,10 @@ def lib():
         L.orc_render_slab.argtypes = [u8p, u32p, f32p, u32p, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                       ctypes.c_uint32, f32p, ctypes.c_int]
         L.orc_render_slab.restype = ctypes.c_uint64
+        L.orc_render_slab_stored.argtypes = [u8p, ctypes.c_int, u32p, ctypes.c_uint32, ctypes.c_uint32, f32p, u32p, ctypes.c_float,
+                                             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p, f32p, u32p,
+                                             ctypes.c_int]
+        L.orc_render_slab_stored.restype = ctypes.c_uint64
         L.orc_compare_volume.argtypes = [u8p, f32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, f32p, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double)]
         L.orc_compare_volume.restype = ctypes.c_float
@@ -209,6 +213,30 @@ def render_slab(voxels_zyxc, cam36, width, height, z_begin, z_end, attenuation=1
     lib().orc_render_slab(_p(v, ctypes.c_uint8), _p(dims, ctypes.c_uint32), _p(cam, ctypes.c_float), _p(tfw, ctypes.c_uint32),
                           ctypes.c_float(attenuation), width, height, int(z_begin), int(z_end), _p(out, ctypes.c_float), nt)
     return out
+
+
+def render_slab_stored(stored, dims_xyz, z_store0, cam36, width, height, z_begin, z_end, crop=None, attenuation=1.0, tf=None,
+                       threads=None):
+    """render_slab from the stored slices alone: `stored` is uint8 (S, Y, X) (scalar density, [b,b,b,b]) or (S, Y, X, 4)
+    holding the slices [z_store0, z_store0 + S) of a dims_xyz volume; crop = (x0, y0, w, h) pixels of the width x height
+    image (default: all).  Returns (f32 partial (h, w, 4), loop iterations per ray (h, w))."""
+    v = np.ascontiguousarray(stored, dtype=np.uint8)
+    scalar = v.ndim == 3
+    S, Y, X = v.shape[:3]
+    dims = np.asarray(dims_xyz, dtype=np.uint32)
+    assert (X, Y) == (int(dims[0]), int(dims[1])) and z_store0 + S <= int(dims[2])
+    crop = (0, 0, width, height) if crop is None else tuple(int(c) for c in crop)
+    cr = np.asarray(crop, dtype=np.uint32)
+    cam = np.ascontiguousarray(cam36, dtype=np.float32)
+    tfw = tf_words(False) if tf is None else np.ascontiguousarray(tf, dtype=np.uint32)
+    out = np.zeros((crop[3], crop[2], 4), dtype=np.float32)
+    steps = np.zeros((crop[3], crop[2]), dtype=np.uint32)
+    nt = threads if threads is not None else max(1, min(16, os.cpu_count() or 1))
+    lib().orc_render_slab_stored(_p(v, ctypes.c_uint8), 1 if scalar else 0, _p(dims, ctypes.c_uint32), int(z_store0), int(z_store0 + S),
+                                 _p(cam, ctypes.c_float), _p(tfw, ctypes.c_uint32), ctypes.c_float(attenuation), width, height,
+                                 int(z_begin), int(z_end), _p(cr, ctypes.c_uint32), _p(out, ctypes.c_float),
+                                 _p(steps, ctypes.c_uint32), nt)
+    return out, steps
 
 
 def ssim_u8(img_a, img_b, data_range):

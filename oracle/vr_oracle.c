@@ -316,6 +316,11 @@ typedef struct {
      * has z in [slab_lo, slab_hi) contribute; every other sample reads as scene() == 0, i.e. adds exactly nothing */
     int slab;
     float slab_lo, slab_hi;
+    /* test-infrastructure form of the same slab render for volumes that do not fit host memory whole: `voxels` holds only
+     * the z slices [z_off, z_off + z_cnt) -- what a slab's samples can touch -- and, with `scalar`, one byte per voxel
+     * standing for [b,b,b,b] (dat.rs:74).  A texel outside the stored range reads as NaN so that a mistake shows. */
+    uint32_t z_off, z_cnt;
+    int scalar;
 } scene_t;
 
 #define MAX_STEP_AMOUNT 5000 /* wgsl:96 */
@@ -323,7 +328,9 @@ static const float STEP_SIZE = 0.001f; /* wgsl:126 */
 
 static float texel(const scene_t *s, int x, int y, int z, int ch)
 {
-    size_t idx = (size_t)x + (size_t)s->dim[0] * ((size_t)y + (size_t)s->dim[1] * (size_t)z);
+    if ((uint32_t)z < s->z_off || (uint32_t)z - s->z_off >= s->z_cnt) return NAN;
+    size_t idx = (size_t)x + (size_t)s->dim[0] * ((size_t)y + (size_t)s->dim[1] * (size_t)((uint32_t)z - s->z_off));
+    if (s->scalar) return (float)s->voxels[idx] / 255.0f;
     return (float)s->voxels[4 * idx + (size_t)ch] / 255.0f; /* Rgba8Unorm decode */
 }
 
@@ -474,9 +481,15 @@ static uint32_t shade_pixel(const scene_t *s, uint32_t px, uint32_t py, uint32_t
  * out_f32 (W*H*4), out_rgba8 (W*H*4), out_steps (W*H) are each optional (NULL to skip).
  * Returns the total number of loop iterations over all rays (the reference-equivalent sample count).
  */
+typedef struct {
+    uint32_t z_off, z_cnt; /* stored slices (the whole volume: 0, dims[2]) */
+    int scalar;            /* 1 byte per voxel */
+    uint32_t crop[4];      /* x0, y0, w, h of the pixels to render; the outputs are w*h */
+} render_opts;
+
 static uint64_t render_impl(const uint8_t *voxels, const uint32_t dims[3], const float cam36[36], const uint32_t tf16[16],
                             float attenuation, uint32_t W, uint32_t H, float *out_f32, uint8_t *out_rgba8,
-                            uint32_t *out_steps, int n_threads, int slab, uint32_t z_begin, uint32_t z_end)
+                            uint32_t *out_steps, int n_threads, int slab, uint32_t z_begin, uint32_t z_end, const render_opts *ro)
 {
     scene_t s;
     memset(&s, 0, sizeof s);
@@ -490,6 +503,10 @@ static uint64_t render_impl(const uint8_t *voxels, const uint32_t dims[3], const
     for (int i = 0; i < 3; ++i) { s.col_a[i] = tf[i]; s.col_b[i] = tf[4 + i]; s.col_c[i] = tf[8 + i]; }
     s.use_tf = tf16[12] != 0;
     s.cam = cam36;
+    s.z_off = ro ? ro->z_off : 0;
+    s.z_cnt = ro ? ro->z_cnt : dims[2];
+    s.scalar = ro ? ro->scalar : 0;
+    const uint32_t cx0 = ro ? ro->crop[0] : 0, cy0 = ro ? ro->crop[1] : 0, cw = ro ? ro->crop[2] : W, chh = ro ? ro->crop[3] : H;
     if (slab) {
         /* world-space bounds of the slices [z_begin, z_end): the box faces at the ends, one shared f32 value between */
         const float Zf = (float)dims[2];
@@ -501,11 +518,12 @@ static uint64_t render_impl(const uint8_t *voxels, const uint32_t dims[3], const
     uint64_t total = 0;
     if (n_threads < 1) n_threads = 1;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : total)
-    for (int64_t py = 0; py < (int64_t)H; ++py) {
-        for (uint32_t px = 0; px < W; ++px) {
+    for (int64_t qy = 0; qy < (int64_t)chh; ++qy) {
+        for (uint32_t qx = 0; qx < cw; ++qx) {
             float c[4];
-            uint32_t it = shade_pixel(&s, px, (uint32_t)py, W, H, c);
-            size_t o = (size_t)py * W + px;
+            const uint32_t px = cx0 + qx, py = cy0 + (uint32_t)qy;
+            uint32_t it = shade_pixel(&s, px, py, W, H, c);
+            size_t o = (size_t)qy * cw + qx;
             total += it;
             if (out_steps) out_steps[o] = it;
             if (out_f32) { out_f32[4 * o] = c[0]; out_f32[4 * o + 1] = c[1]; out_f32[4 * o + 2] = c[2]; out_f32[4 * o + 3] = c[3]; }
@@ -519,7 +537,7 @@ ORC_API uint64_t orc_render(const uint8_t *voxels, const uint32_t dims[3], const
                             float attenuation, uint32_t W, uint32_t H, float *out_f32, uint8_t *out_rgba8,
                             uint32_t *out_steps, int n_threads)
 {
-    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, out_rgba8, out_steps, n_threads, 0, 0, 0);
+    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, out_rgba8, out_steps, n_threads, 0, 0, 0, NULL);
 }
 
 /* The partial image of the z slab [z_begin, z_end) of a sort-last render: the whole volume's sample lattice, only the
@@ -529,7 +547,26 @@ ORC_API uint64_t orc_render_slab(const uint8_t *voxels, const uint32_t dims[3], 
                                  float attenuation, uint32_t W, uint32_t H, uint32_t z_begin, uint32_t z_end, float *out_f32,
                                  int n_threads)
 {
-    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, NULL, NULL, n_threads, 1, z_begin, z_end);
+    return render_impl(voxels, dims, cam36, tf16, attenuation, W, H, out_f32, NULL, NULL, n_threads, 1, z_begin, z_end, NULL);
+}
+
+/* The same partial image from the STORED slices alone -- `stored` holds the slices [z_store0, z_store1) of a dims volume,
+ * one byte per voxel if `scalar` (a DAT density, [b,b,b,b]) else RGBA8 -- and only for the pixels of crop = {x0, y0, w, h}
+ * of the W x H image (outputs are w*h).  For volumes whose whole does not fit host memory (C5: 2048 x 2048 x 4096): a rank's
+ * slab plus its two ghost slices is everything its samples can touch.  out_steps: loop iterations per ray (whole lattice). */
+ORC_API uint64_t orc_render_slab_stored(const uint8_t *stored, int scalar, const uint32_t dims[3], uint32_t z_store0,
+                                        uint32_t z_store1, const float cam36[36], const uint32_t tf16[16], float attenuation,
+                                        uint32_t W, uint32_t H, uint32_t z_begin, uint32_t z_end, const uint32_t crop[4],
+                                        float *out_f32, uint32_t *out_steps, int n_threads)
+{
+    render_opts ro;
+    ro.z_off = z_store0;
+    ro.z_cnt = z_store1 - z_store0;
+    ro.scalar = scalar;
+    for (int i = 0; i < 4; ++i) ro.crop[i] = crop[i];
+    const int whole = z_begin == 0 && z_end == dims[2];
+    return render_impl(stored, dims, cam36, tf16, attenuation, W, H, out_f32, NULL, out_steps, n_threads, whole ? 0 : 1, z_begin,
+                       z_end, &ro);
 }
 
 /* Point sample for unit tests: scene(p) with the given grid (wgsl:199-238) */
@@ -541,6 +578,7 @@ ORC_API void orc_scene(const uint8_t *voxels, const uint32_t dims[3], const floa
     orc_grid_uniform(dims, 1.0f, d4, bmin, bsz, buf);
     memset(&s, 0, sizeof s);
     s.voxels = voxels;
+    s.z_cnt = dims[2];
     for (int i = 0; i < 3; ++i) { s.dim[i] = dims[i]; s.box_min[i] = bmin[i]; s.box_size[i] = bsz[i]; }
     scene(&s, p, out);
 }

@@ -1,0 +1,48 @@
+"""`python bench.py --gpus N` must start N ranks by itself: the launcher branch is run here on CPU
+with the rank body replaced by its GPU-free self-test (VRM_BENCH_LAUNCH_TEST=1: gloo rendezvous, world-size check,
+barrier, max/sum over ranks).  Exactly one JSON line must come back, from rank 0, with n_gpus == N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env["VRM_BENCH_LAUNCH_TEST"] = "1"
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_gpus_n_spawns_n_ranks_and_prints_one_line(n):
+    p = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["launcher_selftest"] is True
+    assert out["max_time"] == float(n) and out["views"] == 256     # max over ranks of 1 + rank; the partition covers every view
+    assert out["steps"] == 2 and out["warmup"] == 1                 # the arguments reached the ranks unchanged
+
+
+def test_single_rank_does_not_spawn():
+    p = _run(["--gpus", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip())
+    assert out["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    # under torch.distributed.run with a different N the ranks must refuse, not silently report WORLD_SIZE
+    p = _run(["--gpus", "4"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0
+    assert "WORLD_SIZE=1" in (p.stderr + p.stdout)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import image_metrics, sphere_cam
+from conftest import have_gpu, image_metrics, sphere_cam
 from volume_renderer_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -298,3 +298,73 @@ def test_resize_that_cannot_be_allocated_leaves_a_usable_context(vr, orc):
         assert list(r.voxel_grid.uniform().dimensions)[:3] == [12, 12, 12]
     finally:
         r.close()
+
+
+def test_draw_waits_for_a_pending_readback_of_its_target(vr, orc):
+    """draw A -> readback_async -> draw B into the same image -> map: the second draw must not overwrite the device image
+    under the copy that is still reading it (write-after-read on img->dev).  The map after a re-draw returns B's pixels,
+    and what an earlier map returned was A's -- never a mix of the two."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    R = 2048                                                      # 16 MiB per image: the copy takes a while
+    r = vr.RayMarcher(0, R, R)
+    r.voxel_grid.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32((64, 64, 64))))
+    r.voxel_grid.attenuation = 30.0
+    r.voxel_grid.update_voxel_grid_buffer()
+    cam_a = vr.uniform_from_array(sphere_cam(orc, 1, 3))
+    cam_b = vr.uniform_from_array(sphere_cam(orc, 5, 6))
+    ref, img = vr.Screenshotter(r, R, R), vr.Screenshotter(r, R, R)
+    r.draw(cam_a, ref)
+    want_a = ref.read()
+    r.draw(cam_b, ref)
+    want_b = ref.read()
+    assert not np.array_equal(want_a, want_b)
+    for _ in range(4):
+        r.draw(cam_a, img)
+        img.screenshot()                                          # copy of A in flight on the copy stream
+        r.draw(cam_b, img)                                        # must wait for that copy
+        assert np.array_equal(img.read(), want_b)                 # latest draw wins, whole image
+        r.draw(cam_a, img)
+        img.screenshot()
+        a_pixels = img.read()                                     # mapped before the next draw: A
+        r.draw(cam_b, img)
+        assert np.array_equal(a_pixels, want_a)
+    img.close()
+    ref.close()
+    r.close()
+
+
+def test_image_outlives_its_context(vr):
+    """vrm_destroy before vrm_image_destroy (Python: RayMarcher.close() while a Screenshotter is still referenced): the
+    image is orphaned, refuses every call but destroy, and destroy does not touch the freed context."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    r = vr.RayMarcher(0, 64, 64)
+    img = vr.Screenshotter(r, 64, 64)
+    r.draw(vr.Camera(1.0).uniform(), img)
+    r.close()
+    with pytest.raises(vr.VrmError) as e:
+        img.read()
+    assert e.value.status == -5 and "context was destroyed" in str(e.value)
+    with pytest.raises(vr.VrmError):
+        img.screenshot()
+    img.close()
+
+
+def test_export_error_path_joins_and_reports(vr, tmp_path):
+    """A failing PNG write in the middle of the export (the directory vanished) must come back as VRM_ERR_IO with every
+    encoder thread joined and every image unmapped -- not terminate the process."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    r = vr.RayMarcher(0, 64, 64)
+    r.voxel_grid.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32((16, 16, 16))))
+    missing = tmp_path / "not_there"
+    from volume_renderer_amd import _ffi
+    org = np.zeros(3, dtype=np.float32)
+    rc = _ffi.lib().vrm_export_sphere(r._h, 4, 4, ctypes.c_float(2.5), org.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                      os.fsencode(str(missing)), 1, 2)     # part 1: no cameras.json, straight to the PNGs
+    assert rc == -4 and "cannot open" in _ffi.lib().vrm_last_error().decode()
+    good = tmp_path / "out"
+    r.export_sphere(4, 4, 2.5, str(good))                          # the context is still usable
+    assert len(list(good.glob("*.png"))) == 12
+    r.close()

@@ -118,3 +118,29 @@ def test_two_rank_gloo_sort_last_exchange(orc):
         full = orc.render(vox, cam, W, H, attenuation=30.0)
         assert np.abs(img[i] - full["f32"]).max() <= 2e-5
         assert np.abs(sortlast.unorm8(img[i]).astype(int) - full["rgba8"].astype(int)).max() <= 1
+
+
+def test_oracle_slab_from_stored_slices_only(orc):
+    """oracle.render_slab_stored (the checker of the true-size C5 GPU test): the partial of a slab rendered from its stored
+    slices alone -- RGBA8 or one byte per voxel, whole image or a crop -- is bit-identical to render_slab on the whole
+    volume, and a texel outside the stored range would show as NaN."""
+    dims = (20, 16, 24)
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32(dims))
+    cam = orc.camera_uniform(orc.sphere_position(1, 3, 8, 8, 2.5))
+    W, H = 48, 40
+    for z0, z1 in [(0, 9), (8, 16), (16, 24)]:
+        s0, s1 = sortlast.stored_range(dims[2], z0, z1)
+        full = orc.render_slab(vox, cam, W, H, z0, z1, attenuation=20.0)
+        part, steps = orc.render_slab_stored(vox[s0:s1], dims, s0, cam, W, H, z0, z1, attenuation=20.0)
+        assert np.array_equal(full, part)
+        crop, csteps = orc.render_slab_stored(vox[s0:s1], dims, s0, cam, W, H, z0, z1, crop=(10, 5, 20, 30), attenuation=20.0)
+        assert np.array_equal(full[5:35, 10:30], crop) and np.array_equal(steps[5:35, 10:30], csteps)
+    # without the ghost slice the filter reaches outside the stored range: NaN, loudly
+    bad, _ = orc.render_slab_stored(vox[8:16], dims, 8, cam, W, H, 8, 16, attenuation=20.0)
+    assert np.isnan(bad).any()
+    # scalar (DAT-style) storage == the replicated RGBA8 volume; whole-volume form == orc.render
+    dens = synth.blobs_scalar_u8(dims)
+    v4 = np.repeat(dens[..., None], 4, axis=3)
+    full = orc.render(v4, cam, W, H, attenuation=20.0, want_steps=True)
+    part, steps = orc.render_slab_stored(dens, dims, 0, cam, W, H, 0, dims[2], attenuation=20.0)
+    assert np.array_equal(full["f32"], part) and np.array_equal(full["steps"], steps)

@@ -1,5 +1,6 @@
 // vrm_api.cpp -- the C ABI of include/vrm.h: context, voxel grid, render targets, draw.
 // Compiled with hipcc; uses the HIP runtime API only (no torch, no CPU fallback).
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -210,6 +211,10 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    // render targets that outlive the context (the reference's Screenshotter is a separate object too, state.rs:161):
+    // nothing of theirs is in flight any more; they keep their memory until vrm_image_destroy and refuse every other call
+    for (vrm_image *img : ctx->images) img->ctx = nullptr;
+    ctx->images.clear();
     for (auto &p : ctx->prof_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -362,6 +367,7 @@ extern "C" int vrm_get_grid_uniform(vrm_ctx *ctx, vrm_grid_uniform *out)
 
 extern "C" int vrm_image_create(vrm_ctx *ctx, uint32_t width, uint32_t height, vrm_image **out_image)
 {
+    return vrm_guard("vrm_image_create", VRM_ERR_INVALID, [&]() -> int {
     int rc = bind(ctx);
     if (rc) return rc;
     REQUIRE(out_image != nullptr, "null argument");
@@ -370,6 +376,7 @@ extern "C" int vrm_image_create(vrm_ctx *ctx, uint32_t width, uint32_t height, v
     vrm_image *img = new (std::nothrow) vrm_image();
     REQUIRE(img != nullptr, "out of host memory");
     img->ctx = ctx;
+    img->device = ctx->device;
     img->width = width;
     img->height = height;
     img->pitch = (((size_t)width * 4 + 255) / 256) * 256; // screenshot.rs:94-96
@@ -382,21 +389,32 @@ extern "C" int vrm_image_create(vrm_ctx *ctx, uint32_t width, uint32_t height, v
         if ((rc = vrm_check_hip(hipMemsetAsync(img->dev, 0, img->pitch * height, ctx->stream), "hipMemsetAsync"))) break;
         if ((rc = vrm_check_hip(hipEventRecord(img->drawn, ctx->stream), "hipEventRecord"))) break;
     } while (0);
+    if (!rc) {
+        try {
+            ctx->images.push_back(img);
+        } catch (const std::bad_alloc &) {
+            vrm_set_error("out of host memory");
+            rc = VRM_ERR_INVALID;
+        }
+    }
     if (rc) {
         vrm_image_destroy(img);
         return rc;
     }
     *out_image = img;
     return VRM_OK;
+    });
 }
 
 extern "C" void vrm_image_destroy(vrm_image *img)
 {
     if (!img) return;
-    if (img->ctx) {
-        (void)hipSetDevice(img->ctx->device);
+    (void)hipSetDevice(img->device);
+    if (img->ctx) { // (an orphan -- its context was destroyed first -- has nothing in flight: vrm_destroy drained the streams)
         (void)hipStreamSynchronize(img->ctx->stream);
         (void)hipStreamSynchronize(img->ctx->copy_stream);
+        auto &v = img->ctx->images;
+        v.erase(std::remove(v.begin(), v.end(), img), v.end());
     }
     if (img->dev) (void)hipFree(img->dev);
     if (img->host) (void)hipHostFree(img->host);
@@ -408,9 +426,18 @@ extern "C" void vrm_image_destroy(vrm_image *img)
     delete img;
 }
 
+#define REQUIRE_LIVE(img)                                                                              \
+    do {                                                                                               \
+        if ((img)->ctx == nullptr) {                                                                   \
+            vrm_set_error("the image's context was destroyed; only vrm_image_destroy is valid on it"); \
+            return VRM_ERR_STATE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
 extern "C" int vrm_image_readback_async(vrm_image *img)
 {
     REQUIRE(img != nullptr, "null image");
+    REQUIRE_LIVE(img);
     int rc = bind(img->ctx);
     if (rc) return rc;
     if (img->mapped) {
@@ -429,6 +456,7 @@ extern "C" int vrm_image_readback_async(vrm_image *img)
 extern "C" int vrm_image_map(vrm_image *img, const uint8_t **rgba8, size_t *pitch)
 {
     REQUIRE(img != nullptr && rgba8 != nullptr && pitch != nullptr, "null argument");
+    REQUIRE_LIVE(img);
     int rc = bind(img->ctx);
     if (rc) return rc;
     if (img->mapped) {
@@ -476,6 +504,7 @@ extern "C" int vrm_image_save_png(vrm_image *img, const char *path)
 extern "C" int vrm_image_read_ray_diagnostics(vrm_image *img, float *geom8)
 {
     REQUIRE(img != nullptr && geom8 != nullptr, "null argument");
+    REQUIRE_LIVE(img);
     int rc = bind(img->ctx);
     if (rc) return rc;
     if (!img->diag_geom) {
@@ -490,6 +519,7 @@ extern "C" int vrm_image_read_ray_diagnostics(vrm_image *img, float *geom8)
 extern "C" int vrm_image_read_diagnostics(vrm_image *img, float *rgba_f32, uint32_t *iterations)
 {
     REQUIRE(img != nullptr, "null image");
+    REQUIRE_LIVE(img);
     int rc = bind(img->ctx);
     if (rc) return rc;
     if (!img->diag_rgba || !img->diag_iters) {
@@ -509,6 +539,7 @@ extern "C" int vrm_image_read_diagnostics(vrm_image *img, float *rgba_f32, uint3
 extern "C" int vrm_image_read_sample_counts(vrm_image *img, uint32_t *executed)
 {
     REQUIRE(img != nullptr && executed != nullptr, "null argument");
+    REQUIRE_LIVE(img);
     int rc = bind(img->ctx);
     if (rc) return rc;
     if (!img->diag_iters) {
@@ -576,7 +607,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     p->packed_alpha = (int32_t)ctx->opt_packed;
 }
 
-extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
+static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
 {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -595,6 +626,11 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
             return VRM_ERR_STATE;
         }
     }
+    // A target whose read-back is still in flight on the copy stream must not be overwritten under it: the draw waits
+    // for the copy (the reference's buffer is mapped/unmapped around each copy, screenshot.rs:58-91, so the case cannot
+    // arise there).  The copy itself stays valid: it holds the image as it was when the read-back was enqueued.
+    for (uint32_t i = 0; i < n; ++i)
+        if (targets[i]->copy_pending) HIP_TRY(hipStreamWaitEvent(ctx->stream, targets[i]->copied, 0));
     const bool diag = ctx->opt_diag != 0;
     if (diag) {
         for (uint32_t i = 0; i < n; ++i) {
@@ -621,12 +657,13 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
         d.diag_geom = diag ? targets[i]->diag_geom : nullptr;
         d.partial_rgba = nullptr;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->views_dev + slot, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
+    VrmViewDesc *dev_views = ctx->views_dev + slot;
+    HIP_TRY(hipMemcpyAsync(dev_views, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
 
     VrmMarchParams p;
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, w, h, targets[0]->pitch);
-    p.views = ctx->views_dev + slot;
+    p.views = dev_views;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->opt_profile) {
@@ -651,6 +688,11 @@ extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, u
         img->copy_pending = false;
     }
     return VRM_OK;
+}
+
+extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
+{
+    return vrm_guard("vrm_draw_batch", VRM_ERR_INVALID, [&]() -> int { return draw_batch_impl(ctx, cameras, n, targets); });
 }
 
 extern "C" int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *target)

@@ -23,8 +23,8 @@ struct VrmGridDev {
     const uint32_t *vox; // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211)
     uint32_t dim[3];
     uint32_t scalar;     // 1 => every voxel has r == g == b == a (DAT volumes, dat.rs:74)
-    const uint8_t *occ;  // max alpha per 8x8x8-voxel cell, x fastest (exact empty-space skipping)
-    uint32_t occ_dim[3]; // ceil(dim / 8)
+    const uint8_t *occ;  // max alpha per 4x4x4-texel cell, x fastest (exact empty-space skipping)
+    uint32_t occ_dim[3]; // ceil(dim / 4)
     // the same voxels in bricks of 4(x) x 4(y) x 2(z) texels = 32 words = one 128-byte line:
     // word = 32*(bx + nbx*(by + nby*bz)) + 16*(z&1) + 4*(y&3) + (x&3), bx = x>>2, by = y>>2, bz = z>>1.
     // A staged box of ~12^3 texels touches ~90 lines of it instead of ~190 of the x-fastest array.

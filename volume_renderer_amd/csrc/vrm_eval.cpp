@@ -72,13 +72,16 @@ int ssd_device(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t row_word
 
 extern "C" int vrm_compare_volume_f32_device(vrm_ctx *ctx, const float *color_czyx_dev, int density_only, float *out_rmse)
 {
+    return vrm_guard("vrm_compare_volume_f32_device", VRM_ERR_INVALID, [&]() -> int {
     REQUIRE(ctx != nullptr && color_czyx_dev != nullptr && out_rmse != nullptr, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     return compare_volume(ctx, color_czyx_dev, density_only, out_rmse);
+    });
 }
 
 extern "C" int vrm_compare_volume_f32(vrm_ctx *ctx, const float *color_czyx, int density_only, float *out_rmse)
 {
+    return vrm_guard("vrm_compare_volume_f32", VRM_ERR_INVALID, [&]() -> int {
     REQUIRE(ctx != nullptr && color_czyx != nullptr && out_rmse != nullptr, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf d;
@@ -86,10 +89,12 @@ extern "C" int vrm_compare_volume_f32(vrm_ctx *ctx, const float *color_czyx, int
     HIP_TRY(hipMalloc(&d.p, bytes));
     HIP_TRY(hipMemcpyAsync(d.p, color_czyx, bytes, hipMemcpyHostToDevice, ctx->stream));
     return compare_volume(ctx, (const float *)d.p, density_only, out_rmse);
+    });
 }
 
 extern "C" int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t n, uint64_t *out_ssd)
 {
+    return vrm_guard("vrm_ssd_u8", VRM_ERR_INVALID, [&]() -> int {
     REQUIRE(ctx != nullptr && out_ssd != nullptr && (n == 0 || (a != nullptr && b != nullptr)), "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     *out_ssd = 0;
@@ -103,11 +108,13 @@ extern "C" int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size
     HIP_TRY(hipMemcpyAsync(da.p, a, n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(db.p, b, n, hipMemcpyHostToDevice, ctx->stream));
     return ssd_device(ctx, (const uint8_t *)da.p, (const uint8_t *)db.p, padded / 4, 1, padded, padded, out_ssd);
+    });
 }
 
 extern "C" int vrm_ssim_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels,
                            double data_range, double *out_ssim)
 {
+    return vrm_guard("vrm_ssim_u8", VRM_ERR_INVALID, [&]() -> int {
     REQUIRE(ctx != nullptr && a != nullptr && b != nullptr && out_ssim != nullptr, "null argument");
     REQUIRE(channels >= 1 && channels <= 4, "channels must be 1..4, got %u", channels);
     // skimage: "win_size exceeds image extent" (win_size = 7)
@@ -133,12 +140,14 @@ extern "C" int vrm_ssim_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, uin
     // per-channel means over the cropped map, then the mean over channels: every channel has the same count
     *out_ssim = sum / (double)items;
     return VRM_OK;
+    });
 }
 
 extern "C" int vrm_image_ssd(vrm_image *a, vrm_image *b, uint64_t *out_ssd, uint64_t *out_count)
 {
+    return vrm_guard("vrm_image_ssd", VRM_ERR_INVALID, [&]() -> int {
     REQUIRE(a != nullptr && b != nullptr && out_ssd != nullptr, "null argument");
-    REQUIRE(a->ctx == b->ctx, "images belong to different contexts");
+    REQUIRE(a->ctx != nullptr && a->ctx == b->ctx, "images belong to different contexts or their context was destroyed");
     REQUIRE(a->width == b->width && a->height == b->height, "image sizes differ (%ux%u vs %ux%u)", a->width, a->height, b->width,
             b->height);
     vrm_ctx *ctx = a->ctx;
@@ -146,6 +155,7 @@ extern "C" int vrm_image_ssd(vrm_image *a, vrm_image *b, uint64_t *out_ssd, uint
     if (out_count) *out_count = (uint64_t)a->width * a->height * 4;
     // both images were drawn on ctx->stream, the reduction is enqueued behind them
     return ssd_device(ctx, (const uint8_t *)a->dev, (const uint8_t *)b->dev, a->width, a->height, a->pitch, b->pitch, out_ssd);
+    });
 }
 
 // ---- PNG reader: 8-bit gray / gray+alpha / RGB / RGBA, non-interlaced (what the exporter and DiffDVR write) ----
@@ -154,6 +164,7 @@ static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint3
 
 extern "C" int vrm_png_read(const char *path, uint32_t *width, uint32_t *height, uint32_t *channels, uint8_t *pixels, size_t capacity)
 {
+    return vrm_guard("vrm_png_read", VRM_ERR_IO, [&]() -> int {
     REQUIRE(path != nullptr && width != nullptr && height != nullptr && channels != nullptr, "null argument");
     FILE *f = fopen(path, "rb");
     if (!f) {
@@ -208,6 +219,12 @@ extern "C" int vrm_png_read(const char *path, uint32_t *width, uint32_t *height,
     *height = h;
     *channels = ch;
     const size_t row = (size_t)w * ch, need = row * h;
+    // a deflate stream expands at most ~1032:1: a header that promises more than the IDAT data can hold is corrupt, and
+    // must not size an allocation
+    if ((row + 1) * (size_t)h > idat.size() * 1040 + 1024) {
+        vrm_set_error("%s: header says %u x %u x %u but the file holds only %zu bytes of image data", path, w, h, ch, idat.size());
+        return VRM_ERR_IO;
+    }
     if (pixels == nullptr) return VRM_OK; // size query
     REQUIRE(capacity >= need, "%s needs %zu bytes, buffer holds %zu", path, need, capacity);
     std::vector<uint8_t> raw((row + 1) * h);
@@ -244,4 +261,5 @@ extern "C" int vrm_png_read(const char *path, uint32_t *width, uint32_t *height,
         }
     }
     return VRM_OK;
+    });
 }

@@ -4,6 +4,7 @@
 // The reference keeps these in Rust (camera.rs, transform.rs, camera_sphere_controller.rs,
 // sphere_screenshot_manager.rs, screenshot.rs, loaders/dat.rs) on top of glam / image / serde_json.
 // Those crates are not vendored; the formulas below follow their published definitions.
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -312,6 +313,7 @@ extern "C" int vrm_sphere_position(uint32_t ix, uint32_t iy, uint32_t x_div, uin
 extern "C" int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, float radius, const float origin[3],
                                  const char *out_dir, uint32_t part, uint32_t n_parts)
 {
+    return vrm_guard("vrm_export_sphere", VRM_ERR_IO, [&]() -> int {
     if (!ctx || !origin || !out_dir || x_div == 0 || y_div < 2 || n_parts == 0 || part >= n_parts) {
         vrm_set_error("vrm_export_sphere: bad argument (x_div >= 1, y_div >= 2, part < n_parts)");
         return VRM_ERR_INVALID;
@@ -386,28 +388,42 @@ extern "C" int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, f
         std::vector<int> res(n, VRM_OK);
         std::vector<std::string> msgs(n);
         std::vector<std::thread> th;
-        for (size_t i = 0; i < n; ++i) {
-            vrm_image *im = imgs[which * bank + i];
-            const uint8_t *pxp = nullptr;
-            size_t pitch = 0;
-            int r = vrm_image_map(im, &pxp, &pitch); // blocks until this image's copy landed
-            if (r) return r;
-            const View *v = mine[first + i];
-            std::string path = dir + "/" + std::to_string(v->ix) + "-" + std::to_string(v->iy) + ".png"; // state.rs:393
-            th.emplace_back([=, &res, &msgs]() {
-                res[i] = vrm_write_png_rgba8(path.c_str(), pxp, im->width, im->height, pitch);
-                if (res[i]) msgs[i] = vrm_last_error();
-            });
+        size_t mapped = 0;
+        int r = VRM_OK;
+        std::string first_msg;
+        // A failure part-way (a HIP error from a map, no thread to be had) must not leave joinable threads behind --
+        // their destructor would terminate the process -- nor threads still reading pinned buffers the caller is
+        // about to free: stop starting work, join what runs, unmap what is mapped, then report.
+        try {
+            for (size_t i = 0; i < n && !r; ++i) {
+                vrm_image *im = imgs[which * bank + i];
+                const uint8_t *pxp = nullptr;
+                size_t pitch = 0;
+                r = vrm_image_map(im, &pxp, &pitch); // blocks until this image's copy landed
+                if (r) {
+                    first_msg = vrm_last_error();
+                    break;
+                }
+                ++mapped;
+                const View *v = mine[first + i];
+                std::string path = dir + "/" + std::to_string(v->ix) + "-" + std::to_string(v->iy) + ".png"; // state.rs:393
+                th.emplace_back([=, &res, &msgs]() {
+                    res[i] = vrm_write_png_rgba8(path.c_str(), pxp, im->width, im->height, pitch);
+                    if (res[i]) msgs[i] = vrm_last_error();
+                });
+            }
+        } catch (const std::exception &e) {
+            r = VRM_ERR_IO;
+            first_msg = std::string("export: ") + e.what();
         }
         for (auto &t : th) t.join();
-        int r = VRM_OK;
-        for (size_t i = 0; i < n; ++i) {
-            (void)vrm_image_unmap(imgs[which * bank + i]);
-            if (res[i] && !r) {
+        for (size_t i = 0; i < mapped; ++i) (void)vrm_image_unmap(imgs[which * bank + i]);
+        for (size_t i = 0; i < n && !r; ++i)
+            if (res[i]) {
                 r = res[i];
-                vrm_set_error("%s", msgs[i].c_str());
+                first_msg = msgs[i];
             }
-        }
+        if (r) vrm_set_error("%s", first_msg.c_str());
         return r;
     };
 
@@ -424,11 +440,13 @@ extern "C" int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, f
     for (auto im : imgs) vrm_image_destroy(im);
     if (rc) vrm_set_error("%s", keep.c_str());
     return rc;
+    });
 }
 
 // loaders/dat.rs:10-82
 extern "C" int vrm_load_dat(vrm_ctx *ctx, const char *dat_path)
 {
+    return vrm_guard("vrm_load_dat", VRM_ERR_IO, [&]() -> int {
     if (!ctx || !dat_path) {
         vrm_set_error("vrm_load_dat: null argument");
         return VRM_ERR_INVALID;
@@ -482,6 +500,15 @@ extern "C" int vrm_load_dat(vrm_ctx *ctx, const char *dat_path)
         return VRM_ERR_IO;
     }
     const size_t need = (size_t)res[0] * res[1] * res[2] * bps;
+    // the header must not size an allocation the file cannot fill
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0 || need == 0 || (uint64_t)st.st_size < (uint64_t)need ||
+        (uint64_t)res[0] * res[1] > ((uint64_t)1 << 40) / res[2]) {
+        fclose(f);
+        vrm_set_error("%s: expected %zu bytes of samples (%u x %u x %u x %u), file has %lld", raw_path.c_str(), need, res[0], res[1],
+                      res[2], bps, (long long)st.st_size);
+        return VRM_ERR_IO;
+    }
     std::vector<uint8_t> raw(need);
     const size_t got = need ? fread(raw.data(), 1, need, f) : 0;
     fclose(f);
@@ -492,4 +519,5 @@ extern "C" int vrm_load_dat(vrm_ctx *ctx, const char *dat_path)
     int rc = vrm_grid_resize(ctx, res[0], res[1], res[2]); // dat.rs:57
     if (rc) return rc;
     return vrm_grid_upload_scalar(ctx, raw.data(), raw.size(), bps);
+    });
 }

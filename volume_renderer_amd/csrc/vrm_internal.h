@@ -1,5 +1,7 @@
 // vrm_internal.h -- host-side objects behind the opaque handles of include/vrm.h.
 #pragma once
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -21,7 +23,7 @@ struct vrm_ctx {
     uint32_t *vox = nullptr; // RGBA8 words, x fastest
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere
-    uint8_t *occ = nullptr;  // max alpha per 8^3 cell, rebuilt whenever the voxels change
+    uint8_t *occ = nullptr;  // max alpha per 4x4x4-texel cell, rebuilt whenever the voxels change
     uint32_t *bricks = nullptr; // the same voxels in 4x4x2-texel bricks of one 128-byte line each (staging source)
     uint32_t *abricks = nullptr; // the alpha channel alone, 4 texels per word, bricked (1-channel march staging source)
     float attenuation = 1.0f;
@@ -34,6 +36,10 @@ struct vrm_ctx {
     uint32_t views_cap = 0;
     hipEvent_t views_free = nullptr;   // signalled when the last batch's descriptor upload was consumed
 
+    // render targets created from this context and not yet destroyed: vrm_destroy orphans them (ctx = nullptr) so that a
+    // later vrm_image_destroy frees their memory without touching the context's streams
+    std::vector<struct vrm_image *> images;
+
     // options
     int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1;
 
@@ -45,7 +51,8 @@ struct vrm_ctx {
 };
 
 struct vrm_image {
-    vrm_ctx *ctx = nullptr;
+    vrm_ctx *ctx = nullptr;      // nullptr once the context was destroyed: only vrm_image_destroy is valid then
+    int device = 0;
     uint32_t width = 0, height = 0;
     size_t pitch = 0;            // bytes, ceil(4w/256)*256 (screenshot.rs:94-96)
     uint32_t *dev = nullptr;     // render target
@@ -60,6 +67,23 @@ struct vrm_image {
 
 void vrm_set_error(const char *fmt, ...);
 int vrm_check_hip(hipError_t e, const char *what);
+
+// "Nothing aborts across the boundary" (include/vrm.h): an entry point whose body can throw (std::vector, std::string,
+// std::thread) runs it through this, so that an allocation failure or a length error comes back as a status.
+template <class F>
+static inline int vrm_guard(const char *entry, int code, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        vrm_set_error("%s: out of host memory", entry);
+    } catch (const std::exception &e) {
+        vrm_set_error("%s: %s", entry, e.what());
+    } catch (...) {
+        vrm_set_error("%s: unknown exception", entry);
+    }
+    return code;
+}
 
 // host helpers implemented in vrm_host.cpp
 int vrm_write_png_rgba8(const char *path, const uint8_t *rgba, uint32_t w, uint32_t h, size_t pitch);

@@ -531,26 +531,32 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
         int x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
         bool none, fits, interior;
-        for (;;) {
-            // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
-            const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
-            n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
-            bool margin_ok = true; // per lane: every step of this chunk stays inside the volume (slab) with margin
+        // texel-space bounding box [lo, hi] of everything `nl` steps of every lane can touch; returns this lane's
+        // "every step stays inside the volume (slab) with margin"
+        auto chunk_box = [&](int nl, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
+            bool margin_ok = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test.
                 // The bounds are floored per lane and reduced as integers: the results land in SGPRs as they are.
                 // (z of a slab-partitioned volume: samples outside the slab's own range fail the test too, so a chunk
                 // that lies in another rank's slab degenerates to `none` and only advances dt)
-                const float ue = __builtin_fmaf((float)n_lane, du[a], ua[a]);
+                const float ue = __builtin_fmaf((float)nl, du[a], ua[a]);
                 const float fl = fminf(ua[a], ue) - 0.01f, fh = fmaxf(ua[a], ue) + 0.01f;
-                int li = (int)floorf(fmaxf(fl, g.u_lo[a] - 0.5f)), hi = (int)floorf(fminf(fh, g.u_hi[a])) + 1;
-                if (n_lane <= 0) { li = 1 << 28; hi = -(1 << 28); }
+                int li = (int)floorf(fmaxf(fl, g.u_lo[a] - 0.5f)), hh = (int)floorf(fminf(fh, g.u_hi[a])) + 1;
+                if (nl <= 0) { li = 1 << 28; hh = -(1 << 28); }
                 else margin_ok = margin_ok && (fl - eps_in[a] >= g.u_lo[a]) && (fh + eps_in[a] <= g.u_hi[a]);
-                wave_minmax(li, hi);
-                ilo[a] = li;
-                ihi[a] = hi;
+                wave_minmax(li, hh);
+                lo[a] = li;
+                hi[a] = hh;
             }
+            return margin_ok;
+        };
+        for (;;) {
+            // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
+            const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
+            n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
+            const bool margin_ok = chunk_box(n_lane, ilo, ihi); // per lane: every step of this chunk stays inside with margin
             interior = __builtin_amdgcn_ballot_w64(!margin_ok) == 0ull;
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-unit boundary: the staging loads are whole 16-byte quads of the bricked volume
@@ -569,13 +575,15 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         if (!fits && !none) { // global-gather fallback chunk: lockstep, 8 steps
             kk = 8;
             n_lane = active ? min(8, steps_left) : 0;
+            // the box above is that of the ONE step that did not fit; the emptiness test below must cover all 8
+            (void)chunk_box(n_lane, ilo, ihi);
         }
 
         // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
         // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
-        // the dt lattice has to advance.  First a look-up in the 8^3-cell max-alpha grid, later the staged texels.
+        // the dt lattice has to advance.  First a look-up in the 4x4x4-texel-cell max-alpha grid, later the staged texels.
         bool empty = none;
-        if (SKIP && !none && (fits || kk <= 8)) {
+        if (SKIP && !none) {
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
             const int c0x = max(ilo[0], 0) >> 2, c0y = max(ilo[1], 0) >> 2, c0z = max(ilo[2], 0) >> 2;
             const int ncx = (min(ihi[0], mxx) >> 2) - c0x + 1, ncy = (min(ihi[1], mxy) >> 2) - c0y + 1,
