@@ -92,6 +92,17 @@ VRM_API int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *
  * frame at a time).  cameras[i] renders into targets[i]; all targets must have the same size. */
 VRM_API int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets);
 
+/* vrm_draw_batch for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  NO COUNTERPART IN THE REFERENCE (wgpu allocates its command buffers and staging per frame).  Same arguments,
+ * same kernels, same image as vrm_draw_batch; the difference is where the march kernel's scratch -- the per-view
+ * descriptors (inverse view-projection, position, output pointers; 120 B per view) -- lives: in a file-scope device array
+ * of the library (30 KiB per GPU, held until the process ends) instead of the ring vrm_create allocated.  The call itself
+ * performs no hipMalloc / hipFree / event creation and no host allocation.  Limits: n <= 256 views per call (larger batches
+ * are VRM_ERR_INVALID; split them); VRM_OPT_DIAGNOSTICS and VRM_OPT_PROFILE are ignored (both allocate).  Every call on a
+ * GPU shares that GPU's array: calls are stream-ordered within one context, but calls from DIFFERENT contexts on the same
+ * GPU that overlap in time race on it -- serialise them (vrm_synchronize) or use vrm_draw_batch. */
+VRM_API int vrm_draw_batch_static(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets);
+
 /* device.poll(Maintain::wait()) (screenshot.rs:62): block until everything enqueued on ctx is done. */
 VRM_API int vrm_synchronize(vrm_ctx *ctx);
 

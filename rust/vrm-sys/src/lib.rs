@@ -45,6 +45,8 @@ extern "C" {
     pub fn vrm_destroy(ctx: *mut vrm_ctx);
     pub fn vrm_draw(ctx: *mut vrm_ctx, camera: *const vrm_camera_uniform, target: *mut vrm_image) -> c_int;
     pub fn vrm_draw_batch(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, targets: *const *mut vrm_image) -> c_int;
+    // the same draw with the kernel's descriptor scratch in a static device array: allocates nothing, n <= 256 (no reference counterpart)
+    pub fn vrm_draw_batch_static(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, targets: *const *mut vrm_image) -> c_int;
     pub fn vrm_synchronize(ctx: *mut vrm_ctx) -> c_int;
     // VoxelGrid (voxel/grid.rs:9-299) and the loaders' rules (loaders/dat.rs, loaders/netcdf.rs)
     pub fn vrm_grid_resize(ctx: *mut vrm_ctx, x: u32, y: u32, z: u32) -> c_int;

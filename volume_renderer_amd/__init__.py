@@ -294,6 +294,15 @@ class RayMarcher:
         hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
         _ffi.check(_ffi.lib().vrm_draw_batch(self._h, cams, n, hs))
 
+    def draw_batch_static(self, camera_uniforms, targets):
+        """vrm_draw_batch_static: the same draw with the kernel's descriptor scratch in a static device array -- no
+        allocation of any kind inside the call; at most 256 views."""
+        n = len(camera_uniforms)
+        assert n == len(targets) and n > 0
+        cams = (CameraUniform * n)(*camera_uniforms)
+        hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
+        _ffi.check(_ffi.lib().vrm_draw_batch_static(self._h, cams, n, hs))
+
     def draw_partial(self, camera_uniforms, width, height, device_ptr):
         """n views as premultiplied f32 RGBA into caller-owned device memory (n*H*W*4 floats); enqueue only.  For a slab
         grid (VoxelGrid.new_slab) this is the slab's partial image of a sort-last render."""

@@ -58,6 +58,7 @@ SYMBOLS = {
     "vrm_destroy": (None, [_vp]),
     "vrm_draw": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), _vp]),
     "vrm_draw_batch": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    "vrm_draw_batch_static": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "vrm_synchronize": (ctypes.c_int, [_vp]),
     "vrm_grid_resize": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "vrm_grid_upload_rgba8": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "vrm_internal.h"
@@ -40,6 +41,33 @@ int vrm_check_hip(hipError_t e, const char *what)
     } while (0)
 
 static const uint32_t kViewRing = 4096; // descriptor ring slots
+
+// ---- the allocation-free draw (include/vrm.h: vrm_draw_batch_static) ------------------------------------------------
+// Scratch of the march kernel = the view descriptors of the batch (VrmViewDesc: inverse view-projection, position,
+// output pointers), which vrm_draw_batch stages in a ring the library hipMalloc'ed at vrm_create.  Here they live in
+// a file-scope device array: every GPU this library runs on holds its own copy (30 KiB) until the process ends.  The
+// array's NAME is a host-side stand-in, not a device address; the address on each device comes from
+// hipGetSymbolAddress, once per device with that device current (scratch_init, called by vrm_create), and only that
+// pointer is ever handed to a copy or a kernel.
+#define VRM_STATIC_MAX_VIEWS 256
+static __device__ __align__(256) unsigned char scratch[VRM_STATIC_MAX_VIEWS * sizeof(VrmViewDesc)];
+static const int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+static int scratch_init(int device, void **out)
+{
+    REQUIRE(device >= 0 && device < kMaxDevices, "device ordinal %d beyond the %d this library tracks", device, kMaxDevices);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))); // the current device's copy (the caller made `device` current)
+        REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address for the descriptor scratch");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return VRM_OK;
+}
 
 extern "C" const char *vrm_last_error(void) { return g_err; }
 extern "C" const char *vrm_version(void) { return "vrm 0.1 (gfx950)"; }
@@ -189,6 +217,7 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
         if ((rc = vrm_check_hip(hipSetDevice(ctx->device), "hipSetDevice"))) break;
         if ((rc = vrm_check_hip(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
         if ((rc = vrm_check_hip(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
+        if ((rc = scratch_init(ctx->device, &ctx->scratch))) break; // this device's copy of the static descriptor scratch
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
@@ -607,12 +636,17 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     p->packed_alpha = (int32_t)ctx->opt_packed;
 }
 
-static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
+static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets, bool use_static)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     REQUIRE(cameras != nullptr && targets != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
+    if (use_static) {
+        REQUIRE(n <= VRM_STATIC_MAX_VIEWS, "vrm_draw_batch_static: %u views exceed the static descriptor scratch (at most %d per call)",
+                n, VRM_STATIC_MAX_VIEWS);
+        REQUIRE(ctx->scratch != nullptr, "the descriptor scratch of device %d was not initialised", ctx->device);
+    }
     if (!ctx->vox) {
         vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
         return VRM_ERR_STATE;
@@ -631,7 +665,9 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     // arise there).  The copy itself stays valid: it holds the image as it was when the read-back was enqueued.
     for (uint32_t i = 0; i < n; ++i)
         if (targets[i]->copy_pending) HIP_TRY(hipStreamWaitEvent(ctx->stream, targets[i]->copied, 0));
-    const bool diag = ctx->opt_diag != 0;
+    // (the allocation-free form neither allocates diagnostics buffers nor creates profiling events: both switches are
+    // ignored there)
+    const bool diag = ctx->opt_diag != 0 && !use_static;
     if (diag) {
         for (uint32_t i = 0; i < n; ++i) {
             vrm_image *img = targets[i];
@@ -657,7 +693,10 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
         d.diag_geom = diag ? targets[i]->diag_geom : nullptr;
         d.partial_rgba = nullptr;
     }
-    VrmViewDesc *dev_views = ctx->views_dev + slot;
+    // the pinned source slots advance through the ring either way (an async copy reads them later); the device side is
+    // the ring slot, or always the start of the static scratch -- stream order keeps the previous launch's reads ahead
+    // of this copy
+    VrmViewDesc *dev_views = use_static ? reinterpret_cast<VrmViewDesc *>(ctx->scratch) : ctx->views_dev + slot;
     HIP_TRY(hipMemcpyAsync(dev_views, ctx->views_host + slot, sizeof(VrmViewDesc) * n, hipMemcpyHostToDevice, ctx->stream));
 
     VrmMarchParams p;
@@ -666,7 +705,7 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     p.views = dev_views;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->opt_profile) {
+    if (ctx->opt_profile && !use_static) {
         if (ctx->prof_used == ctx->prof_events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a));
@@ -692,7 +731,12 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
 
 extern "C" int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
 {
-    return vrm_guard("vrm_draw_batch", VRM_ERR_INVALID, [&]() -> int { return draw_batch_impl(ctx, cameras, n, targets); });
+    return vrm_guard("vrm_draw_batch", VRM_ERR_INVALID, [&]() -> int { return draw_batch_impl(ctx, cameras, n, targets, false); });
+}
+
+extern "C" int vrm_draw_batch_static(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets)
+{
+    return draw_batch_impl(ctx, cameras, n, targets, true); // nothing in this path allocates or throws
 }
 
 extern "C" int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *target)

@@ -34,6 +34,7 @@ struct vrm_ctx {
     VrmViewDesc *views_dev = nullptr;
     VrmViewDesc *views_host = nullptr; // pinned
     uint32_t views_cap = 0;
+    void *scratch = nullptr;           // this device's address of the static descriptor scratch (vrm_draw_batch_static)
     hipEvent_t views_free = nullptr;   // signalled when the last batch's descriptor upload was consumed
 
     // render targets created from this context and not yet destroyed: vrm_destroy orphans them (ctx = nullptr) so that a
