@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvrm.so")
+# VRM_LIB: another build of the same library (kernel A/B runs of tools/ab_builds.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("VRM_LIB") or os.path.join(_HERE, "libvrm.so")
 
 VRM_OK = 0
 VRM_ERR_INVALID = -1

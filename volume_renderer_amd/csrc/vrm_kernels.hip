@@ -369,6 +369,33 @@ __device__ __forceinline__ void wave_minmax(int &lo, int &hi)
     lo = __builtin_amdgcn_readlane(lo, 63);
     hi = __builtin_amdgcn_readlane(hi, 63);
 }
+// three (min, max) pairs at once: six independent chains, so every stage's dependent instruction is five others away
+// and no wait states need padding (a chunk prologue reduces the box bounds of all three axes)
+#define VRM_DPP_STAGE6(CTRL)                                         \
+    "v_min_i32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"            \
+    "v_min_i32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_i32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"            \
+    "v_min_i32_dpp %4, %4, %4 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_i32_dpp %5, %5, %5 " CTRL " bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_minmax3(int lo[3], int hi[3])
+{
+    asm volatile("s_nop 1\n\t"
+                 VRM_DPP_STAGE6("quad_perm:[1,0,3,2] row_mask:0xf")
+                 VRM_DPP_STAGE6("quad_perm:[2,3,0,1] row_mask:0xf")
+                 VRM_DPP_STAGE6("row_half_mirror row_mask:0xf")
+                 VRM_DPP_STAGE6("row_mirror row_mask:0xf")
+                 VRM_DPP_STAGE6("row_bcast:15 row_mask:0xa")
+                 VRM_DPP_STAGE6("row_bcast:31 row_mask:0xc")
+                 "s_nop 1"
+                 : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = __builtin_amdgcn_readlane(lo[a], 63);
+        hi[a] = __builtin_amdgcn_readlane(hi[a], 63);
+    }
+}
+#undef VRM_DPP_STAGE6
 #undef VRM_DPP_MINMAX
 #undef VRM_DPP_STAGE2
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -460,6 +487,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         rs[a] = ray.rd[a] * g.tex_scale[a];
         du[a] = rs[a] * (VRM_STEP_SIZE * 1.01f);
     }
+    // the ray origin in absolute texel coordinates: u(dt) = dt*rs + bla is the coordinate every staged sample is filtered at
+    float bla[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) bla[a] = __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]);
     // Front alignment.  Rays start on the entry faces of the box, so "the same number of steps for every ray" keeps
     // the wave's samples on a copy of those faces: seen at a grazing angle an 8x8-pixel tile is spread over 40+
     // texels along the rays and no chunk ever fits the tile.  Instead the wave advances a plane perpendicular to its
@@ -496,6 +527,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
     const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
     int steps_left = VRM_MAX_STEP_AMOUNT; // wgsl:139: at most 5000 iterations per ray
+#ifdef VRM_AB_ADAPT_KK
+    int kk_start = (int)P.chunk_steps;    // first chunk length tried: what fitted last time, grown again while the tile has room
+#endif
 
     for (;;) {
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
@@ -526,7 +560,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         }
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
+#ifdef VRM_AB_ADAPT_KK
+        int kk = kk_start;
+#else
         int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane
+#endif
         int n_lane;                  // steps of this lane in this chunk
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
         int x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
@@ -546,10 +584,15 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                 int li = (int)floorf(fmaxf(fl, g.u_lo[a] - 0.5f)), hh = (int)floorf(fminf(fh, g.u_hi[a])) + 1;
                 if (nl <= 0) { li = 1 << 28; hh = -(1 << 28); }
                 else margin_ok = margin_ok && (fl - eps_in[a] >= g.u_lo[a]) && (fh + eps_in[a] <= g.u_hi[a]);
+#ifdef VRM_AB_SPLIT_REDUCE
                 wave_minmax(li, hh);
+#endif
                 lo[a] = li;
                 hi[a] = hh;
             }
+#ifndef VRM_AB_SPLIT_REDUCE
+            wave_minmax3(lo, hi);
+#endif
             return margin_ok;
         };
         for (;;) {
@@ -572,6 +615,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             if (fits || none || kk == 1) break;
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
+#ifdef VRM_AB_ADAPT_KK
+        if (fits) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
+#endif
         if (!fits && !none) { // global-gather fallback chunk: lockstep, 8 steps
             kk = 8;
             n_lane = active ? min(8, steps_left) : 0;
@@ -706,65 +752,63 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 
         // ---- the chunk's steps: lane l takes n_lane of them -------------------------------------------
         if (fits) {
-            // Texel coordinate relative to the staged box.  The sample POSITION p = ro + rd*dt and the in-box test
-            // must be the oracle's exact operation sequence, but they only matter where a sample can fall outside
-            // the box; the texel coordinate itself feeds continuous arithmetic only.  So a chunk whose whole box
-            // lies inside the volume with margin ("interior", the common case) skips p and the test and takes
-            // u = dt*(rd*scale) + (ro*scale + bias - box origin) in one FMA per axis.
-            const float fpx = (float)pitch, fsl = (float)slice;
-            // word address of the last corner cell (PACKED: of the last word a sample's texel x can lie in)
-            const float amax = (float)((nz - 2) * slice + (ny - 2) * pitch + (nx - (PACKED ? 1 : 2)));
+            // Texel coordinate of a sample.  The sample POSITION p = ro + rd*dt and the in-box test must be the
+            // oracle's exact operation sequence, but they only matter where a sample can fall outside the box: a chunk
+            // whose whole box lies inside the volume with margin ("interior", the common case) skips both.  The
+            // coordinate that feeds the filter -- continuous arithmetic -- is u = dt*(rd*scale) + (ro*scale + bias), one
+            // FMA per axis, in ABSOLUTE texel units and by the same formula in interior and border chunks; floor(u) and
+            // the weights u - floor(u) come from it, and only the integer cell index is made relative to the staged box
+            // (exact).  So what a sample contributes does not depend on how the march was cut into chunks or where a
+            // chunk's box starts: any chunking, data-dependent ones included, gives bit-identical accumulators.
+            const float o1 = (float)ilo[1], o2 = (float)ilo[2];
+            const float fpx4 = (float)(4 * pitch), fsl4 = (float)(4 * slice);
+            const float x04 = -4.0f * (float)x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
+            const int pitch4 = 4 * pitch, slice4 = 4 * slice;
+            // byte address of the last corner cell (PACKED: of the last word a sample's texel x can lie in)
+            const float amax4 = (float)(4 * ((nz - 2) * slice + (ny - 2) * pitch + (nx - (PACKED ? 1 : 2))));
+            const char *tile_b = reinterpret_cast<const char *>(tile);
+            auto ld = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(tile_b + byte_off); };
             auto steps = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
-                float bl[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    bl[a] = (INTERIOR ? __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]) : g.tex_bias[a]) -
-                            (float)(a == 0 ? (PACKED ? 4 * x0u : x0u) : ilo[a]);
                 for (int j = 0; j < kk; ++j) {
                     if (j < n_lane && active) {
                         if (DIAG) ++iters;
-                        float u0, u1, u2;
                         bool inside = true;
-                        if constexpr (INTERIOR) {
-                            u0 = __builtin_fmaf(dt, rs[0], bl[0]);
-                            u1 = __builtin_fmaf(dt, rs[1], bl[1]);
-                            u2 = __builtin_fmaf(dt, rs[2], bl[2]);
-                        } else {
+                        if constexpr (!INTERIOR) {
                             const float p0 = ray.ro[0] + ray.rd[0] * dt;
                             const float p1 = ray.ro[1] + ray.rd[1] * dt;
                             const float p2 = ray.ro[2] + ray.rd[2] * dt;
                             inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
                                      (p1 < g.box_max[1]) & (p2 < g.in_max_z);
-                            u0 = __builtin_fmaf(p0, g.tex_scale[0], bl[0]);
-                            u1 = __builtin_fmaf(p1, g.tex_scale[1], bl[1]);
-                            u2 = __builtin_fmaf(p2, g.tex_scale[2], bl[2]);
                         }
                         bool done = false;
                         if (inside) {
                             if (DIAG) { ++n_inside; ++n_exec; }
+                            const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
+                            const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
+                            const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
                             // (PACKED: the column is the word floor(x / 4); byte x & 3 of it and the byte after)
                             const float fc = PACKED ? floorf(f0 * 0.25f) : f0;
-                            const float af = __builtin_fmaf(f2, fsl, __builtin_fmaf(f1, fpx, fc)); // exact: small integers
-                            const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax);
-                            const int a1 = a0 + pitch, a2 = a0 + slice, a3 = a2 + pitch;
+                            const float af = __builtin_fmaf(f2 - o2, fsl4, __builtin_fmaf(f1 - o1, fpx4, __builtin_fmaf(fc, 4.0f, x04))); // exact: small integers
+                            const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax4);
+                            const int a1 = a0 + pitch4, a2 = a0 + slice4, a3 = a2 + pitch4;
                             if constexpr (PACKED) {
                                 const uint32_t sh = (uint32_t)(int)f0 & 3u;
                                 uint32_t w[4];
-                                w[0] = __builtin_amdgcn_alignbyte(tile[a0 + 1], tile[a0], sh);
-                                w[1] = __builtin_amdgcn_alignbyte(tile[a1 + 1], tile[a1], sh);
-                                w[2] = __builtin_amdgcn_alignbyte(tile[a2 + 1], tile[a2], sh);
-                                w[3] = __builtin_amdgcn_alignbyte(tile[a3 + 1], tile[a3], sh);
+                                w[0] = __builtin_amdgcn_alignbyte(ld(a0 + 4), ld(a0), sh);
+                                w[1] = __builtin_amdgcn_alignbyte(ld(a1 + 4), ld(a1), sh);
+                                w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
+                                w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
                                 done = shade_packed<USE_TF>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
                             } else {
                                 uint32_t c[8];
-                                c[0] = tile[a0]; c[1] = tile[a0 + 1];
-                                c[2] = tile[a1]; c[3] = tile[a1 + 1];
-                                c[4] = tile[a2]; c[5] = tile[a2 + 1];
-                                c[6] = tile[a3]; c[7] = tile[a3 + 1];
+                                c[0] = ld(a0); c[1] = ld(a0 + 4);
+                                c[2] = ld(a1); c[3] = ld(a1 + 4);
+                                c[4] = ld(a2); c[5] = ld(a2 + 4);
+                                c[6] = ld(a3); c[7] = ld(a3 + 4);
                                 done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
                             }
                         }
