@@ -106,7 +106,8 @@ static int grid_alloc_buffers(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     const size_t words = (size_t)x * y * z;
     const uint32_t xyz[3] = {x, y, z};
     HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
-    HIP_TRY(hipMalloc((void **)&ctx->occ, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 3) / 4)));
+    uint32_t occ_off[VRM_OCC_LEVELS];
+    HIP_TRY(hipMalloc((void **)&ctx->occ, vrm_occupancy_bytes(xyz, occ_off)));
     HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
     HIP_TRY(hipMalloc((void **)&ctx->abricks, vrm_alpha_bricks_bytes(xyz)));
     ctx->vox_words = words;
@@ -593,6 +594,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     g.vox = ctx->vox;
     g.scalar = ctx->scalar ? 1u : 0u;
     g.occ = ctx->occ;
+    (void)vrm_occupancy_bytes(ctx->dim, g.occ_off);
     g.bricks = ctx->bricks;
     g.nbx = (ctx->dim[0] + 3) / 4;
     g.abricks = ctx->abricks;

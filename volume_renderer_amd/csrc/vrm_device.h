@@ -6,6 +6,7 @@
 
 #define VRM_MAX_STEP_AMOUNT 5000 /* raymarcher.wgsl:96 */
 #define VRM_STEP_SIZE 0.001f     /* raymarcher.wgsl:126 */
+#define VRM_OCC_LEVELS 4         /* levels of the occupancy max pyramid (cells of 4, 8, 16, 32 texels) */
 
 // One entry per view of a batch, resident in device memory (read through the scalar cache).
 struct VrmViewDesc {
@@ -23,8 +24,11 @@ struct VrmGridDev {
     const uint32_t *vox; // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211)
     uint32_t dim[3];
     uint32_t scalar;     // 1 => every voxel has r == g == b == a (DAT volumes, dat.rs:74)
-    const uint8_t *occ;  // max alpha per 4x4x4-texel cell, x fastest (exact empty-space skipping)
+    const uint8_t *occ;  // max alpha per 4x4x4-texel cell, x fastest (exact empty-space skipping): level 0 of a max pyramid
     uint32_t occ_dim[3]; // ceil(dim / 4)
+    // level L (1 .. VRM_OCC_LEVELS-1) holds the max over 2^L x 2^L x 2^L level-0 cells, dims ceil(occ_dim / 2^L), at byte
+    // offset occ_off[L] of `occ`: the emptiness test of a chunk 2^L times as deep looks at as many cells as a plain one
+    uint32_t occ_off[4];
     // the same voxels in bricks of 4(x) x 4(y) x 2(z) texels = 32 words = one 128-byte line:
     // word = 32*(bx + nbx*(by + nby*bz)) + 16*(z&1) + 4*(y&3) + (x&3), bx = x>>2, by = y>>2, bz = z>>1.
     // A staged box of ~12^3 texels touches ~90 lines of it instead of ~190 of the x-fastest array.
@@ -68,6 +72,8 @@ struct VrmMarchParams {
 // launchers implemented in vrm_kernels.hip
 hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int variant, bool diagnostics, bool skip_empty,
                             hipStream_t stream);
+// bytes of the occupancy pyramid of a dim[0] x dim[1] x dim[2] volume; off[L] = byte offset of level L
+size_t vrm_occupancy_bytes(const uint32_t dim[3], uint32_t off[VRM_OCC_LEVELS]);
 hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream);
 hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *bricks, hipStream_t stream);
 // bytes of the packed alpha bricks of a dim[0] x dim[1] x dim[2] volume, and their builder

@@ -15,6 +15,13 @@
 
 #pragma clang fp contract(off)
 
+#ifndef VRM_SKIP_MAX_LEVEL
+#define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
+#endif
+#ifndef VRM_SKIP_ESCALATE
+#define VRM_SKIP_ESCALATE 1  /* consecutive empty chunks at one level before the next level is tried */
+#endif
+
 namespace {
 
 constexpr int TILE = 16;        // variant 0: workgroup = 16x16 pixels = 4 waves, each wave an 8x8 pixel tile
@@ -527,6 +534,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
     const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
     int steps_left = VRM_MAX_STEP_AMOUNT; // wgsl:139: at most 5000 iterations per ray
+    // Empty space in long strides.  After an empty chunk the next one is tried 2^lvl times as deep and tested against level
+    // lvl of the occupancy pyramid (cells 2^lvl times as wide: as many look-ups as a plain chunk); a deeper chunk that is not
+    // empty costs one prologue and drops back to lvl 0, where chunks are staged and sampled.  How the march is cut into
+    // chunks does not change what a sample contributes (see the steps below), so this is as exact as plain skipping.
+    int lvl = 0, lvl_run = 0;
 #ifdef VRM_AB_ADAPT_KK
     int kk_start = (int)P.chunk_steps;    // first chunk length tried: what fitted last time, grown again while the tile has room
 #endif
@@ -563,7 +575,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #ifdef VRM_AB_ADAPT_KK
         int kk = kk_start;
 #else
-        int kk = (int)P.chunk_steps; // chunk length: the steps of the rear-most lane
+        int kk = (int)P.chunk_steps << lvl; // chunk length: the steps of the rear-most lane
 #endif
         int n_lane;                  // steps of this lane in this chunk
         int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
@@ -612,13 +624,13 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             slice += (slice & 4) ? 0 : 4;
             // (PACKED reads the word after a sample's word as well: keep one word of the tile spare)
             fits = !none && pitch <= PX_MAX && (long long)nz * slice + (PACKED ? 1 : 0) <= (long long)CAP;
-            if (fits || none || kk == 1) break;
+            if (fits || none || kk == 1 || lvl > 0) break; // (a deep empty-space probe is never staged: it need not fit)
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
 #ifdef VRM_AB_ADAPT_KK
         if (fits) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
 #endif
-        if (!fits && !none) { // global-gather fallback chunk: lockstep, 8 steps
+        if (!fits && !none && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
             kk = 8;
             n_lane = active ? min(8, steps_left) : 0;
             // the box above is that of the ONE step that did not fit; the emptiness test below must cover all 8
@@ -630,12 +642,16 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         // the dt lattice has to advance.  First a look-up in the 4x4x4-texel-cell max-alpha grid, later the staged texels.
         bool empty = none;
         if (SKIP && !none) {
+            const int sh = 2 + lvl; // cells of level lvl are 4 << lvl texels wide
             const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const int c0x = max(ilo[0], 0) >> 2, c0y = max(ilo[1], 0) >> 2, c0z = max(ilo[2], 0) >> 2;
-            const int ncx = (min(ihi[0], mxx) >> 2) - c0x + 1, ncy = (min(ihi[1], mxy) >> 2) - c0y + 1,
-                      ncz = (min(ihi[2], mxz) >> 2) - c0z + 1;
+            const int c0x = max(ilo[0], 0) >> sh, c0y = max(ilo[1], 0) >> sh, c0z = max(ilo[2], 0) >> sh;
+            const int ncx = (min(ihi[0], mxx) >> sh) - c0x + 1, ncy = (min(ihi[1], mxy) >> sh) - c0y + 1,
+                      ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
             const int ncxy = ncx * ncy, nc = ncxy * ncz;
-            if (nc <= 128) { // up to two 4^3-texel cells per lane
+            if (nc <= 128) { // up to two cells per lane
+                const uint32_t rnd = (1u << lvl) - 1u;
+                const size_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
+                const uint8_t *occl = g.occ + g.occ_off[lvl];
                 const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
                 bool occ = false;
 #pragma unroll
@@ -644,11 +660,16 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     if (c < nc) {
                         const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
                         const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
-                        occ |= g.occ[((size_t)(c0z + cz) * g.occ_dim[1] + (size_t)(c0y + cy)) * g.occ_dim[0] + (size_t)(c0x + cx)] != 0;
+                        occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * od0 + (size_t)(c0x + cx)] != 0;
                     }
                 }
                 empty = __builtin_amdgcn_ballot_w64(occ) == 0ull;
             }
+        }
+        if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
+            lvl = 0;
+            lvl_run = 0;
+            continue; // nothing was advanced
         }
 
 #ifdef VRM_TIMING_NO_STAGE // timing build: prologue + dt advance only
@@ -747,8 +768,13 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             }
             steps_left -= n_lane; // a lane that stopped early is inactive anyway
             active = active && steps_left > 0;
+            if (SKIP && VRM_SKIP_MAX_LEVEL > 0) {
+                // (level L exists only if the pyramid fits 32-bit offsets: occ_off[L] != 0)
+                if (++lvl_run >= VRM_SKIP_ESCALATE && lvl < VRM_SKIP_MAX_LEVEL && g.occ_off[lvl + 1] != 0u) { ++lvl; lvl_run = 0; }
+            }
             continue;
         }
+        lvl_run = 0;
 
         // ---- the chunk's steps: lane l takes n_lane of them -------------------------------------------
         if (fits) {
@@ -835,9 +861,10 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                     bool done = false;
                     if (inside) {
                         if (DIAG) { ++n_inside; ++n_exec; }
-                        const float u0 = __builtin_fmaf(p0, g.tex_scale[0], g.tex_bias[0]);
-                        const float u1 = __builtin_fmaf(p1, g.tex_scale[1], g.tex_bias[1]);
-                        const float u2 = __builtin_fmaf(p2, g.tex_scale[2], g.tex_bias[2]);
+                        // the same filter coordinate as the staged path: which path a sample takes depends on the chunking
+                        const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
+                        const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
+                        const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
                         fetch_global(g, (int)f0, (int)f1, (int)f2, c);
@@ -965,6 +992,24 @@ __global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__r
         v = max(v, (uint32_t)__shfl_xor((int)v, 16, 64));
         const uint32_t cx = rx * 2u + (lx >> 2), cy = ry * 2u + (ly >> 2), cz = rz * 2u + (uint32_t)h;
         if ((lx & 3u) == 0 && (ly & 3u) == 0 && cx < ox_n && cy < oy_n && cz < oz_n) occ[((size_t)cz * oy_n + cy) * ox_n + cx] = (uint8_t)v;
+    }
+}
+
+// one level of the occupancy max pyramid from the level below: dst cell = max of the (up to) 2x2x2 src cells it covers
+__global__ void __launch_bounds__(256) build_occupancy_mip_kernel(const uint8_t *__restrict__ src, uint32_t sx, uint32_t sy, uint32_t sz,
+                                                                 uint8_t *__restrict__ dst, uint32_t dx, uint32_t dy, uint32_t dz)
+{
+    const size_t n = (size_t)dx * dy * dz, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t z = (uint32_t)(i / ((size_t)dx * dy)), r = (uint32_t)(i - (size_t)z * dx * dy), y = r / dx, x = r - y * dx;
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < 2u; ++k)
+            for (uint32_t j = 0; j < 2u; ++j)
+                for (uint32_t l = 0; l < 2u; ++l) {
+                    const uint32_t cx = min(2u * x + l, sx - 1u), cy = min(2u * y + j, sy - 1u), cz = min(2u * z + k, sz - 1u);
+                    m = max(m, (uint32_t)src[((size_t)cz * sy + cy) * sx + cx]);
+                }
+        dst[i] = (uint8_t)m;
     }
 }
 
@@ -1261,11 +1306,37 @@ hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim
     return hipGetLastError();
 }
 
+size_t vrm_occupancy_bytes(const uint32_t dim[3], uint32_t off[VRM_OCC_LEVELS])
+{
+    size_t total = 0;
+    for (int l = 0; l < VRM_OCC_LEVELS; ++l) {
+        size_t n = 1;
+        for (int a = 0; a < 3; ++a) n *= (size_t)((((dim[a] + 3) / 4) + (1u << l) - 1u) >> l);
+        off[l] = (uint32_t)total;      // level 0 of a 2^40-texel volume is 2^34 bytes: the coarser levels start beyond 4 GiB there,
+        total += (n + 255) & ~(size_t)255; // which the march kernel checks before using them (occ_off[l] == 0 for l > 0 => level unused)
+    }
+    if (total > 0xffffffffull)
+        for (int l = 1; l < VRM_OCC_LEVELS; ++l) off[l] = 0;
+    return total;
+}
+
 hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
 {
     const uint32_t rx = (dim[0] + 7) / 8, ry = (dim[1] + 7) / 8, rz = (dim[2] + 7) / 8;
-    hipLaunchKernelGGL(build_occupancy_kernel, dim3(rx * ry * rz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], rx, ry,
-                       (dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4, occ);
+    const uint32_t od[3] = {(dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4};
+    hipLaunchKernelGGL(build_occupancy_kernel, dim3(rx * ry * rz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], rx, ry, od[0], od[1],
+                       od[2], occ);
+    uint32_t off[VRM_OCC_LEVELS];
+    (void)vrm_occupancy_bytes(dim, off);
+    for (int l = 1; l < VRM_OCC_LEVELS && off[l] != 0; ++l) {
+        uint32_t s[3], d[3];
+        for (int a = 0; a < 3; ++a) {
+            s[a] = (od[a] + (1u << (l - 1)) - 1u) >> (l - 1);
+            d[a] = (od[a] + (1u << l) - 1u) >> l;
+        }
+        hipLaunchKernelGGL(build_occupancy_mip_kernel, dim3(stream_blocks((size_t)d[0] * d[1] * d[2])), dim3(256), 0, stream,
+                           occ + off[l - 1], s[0], s[1], s[2], occ + off[l], d[0], d[1], d[2]);
+    }
     return hipGetLastError();
 }
 
