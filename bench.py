@@ -174,6 +174,81 @@ def run_c5(a):
         dist.destroy_process_group()
 
 
+def run_c1(a):
+    """C1 (BASELINE.json configs[0]): synthetic 128^3 uint8 DAT volume, ONE 512 x 512 view -- (ix, iy) =
+    (1, 3) of the 8 x 8 sphere at radius 2.5, attenuation 1, transfer function off -- on the CPU path with the core count
+    stated, and the HIP path on the same view beside it.  The CPU path is oracle/vr_oracle.c (a restatement: the wgpu
+    reference on a software adapter cannot be built here); one step = that one view."""
+    import numpy as np
+    import torch  # noqa: F401  (first: the HIP library then shares torch's libamdhip64)
+
+    import oracle
+    import volume_renderer_amd as vr
+    from volume_renderer_amd import synth
+
+    D, R = 128, 512
+    dens = synth.blobs_scalar_u8((D, D, D))
+    vox = np.repeat(dens[..., None], 4, axis=3)                      # [b,b,b,b] (loaders/dat.rs:74)
+    cam36 = oracle.camera_uniform(oracle.sphere_position(1, 3, 8, 8, 2.5))
+    threads = max(1, min(oracle.lib().orc_max_threads(), os.cpu_count() or 1, 64))
+    t0 = time.perf_counter()
+    reps, ref = 0, None
+    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 50):
+        ref = oracle.render(vox, cam36, R, R, want_f32=False, threads=threads)
+        reps += 1
+    cpu_s = (time.perf_counter() - t0) / reps
+    rm = vr.RayMarcher(0, R, R)
+    rm.set_option(vr.OPT_KERNEL, a.kernel)
+    rm.set_option(vr.OPT_SKIP_EMPTY, a.skip_empty)
+    rm.voxel_grid.upload_scalar(dens.reshape(-1), (D, D, D), 1)      # the DAT ingest path (vrm_grid_upload_scalar)
+    cam = vr.uniform_from_array(cam36)
+    img = vr.Screenshotter(rm, R, R)
+    n_ref = rm.count_reference_samples([cam], R, R)
+    for _ in range(max(1, a.warmup)):
+        rm.draw(cam, img)
+        img.screenshot()
+        img.wait()
+    rm.set_option(vr.OPT_PROFILE, 1)
+    rm.profile_read()
+    steps = max(a.steps, 20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rm.draw(cam, img)
+        img.screenshot()
+        img.wait()                                                    # one view per "frame", read back, like the reference's export
+    rm.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = rm.profile_read()
+    got = img.read()
+    d = np.abs(got.astype(np.int32) - ref["rgba8"].astype(np.int32))
+    b_alg = D * D * D * 1 + R * R * 4                                 # packed 1-channel march: 1 B per voxel + the RGBA8 image
+    achieved = b_alg * launches / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "views/s", "value": round(steps / elapsed, 3), "unit": "views/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C1: {D}^3 uint8 DAT-style volume (blobs seed {synth.DEFAULT_SEED}), single {R}x{R} view (1,3) of the 8x8 "
+                               f"sphere, radius 2.5, attenuation 1.0, transfer function off; one draw + read-back per step",
+                   "volume": [D, D, D], "image": [R, R], "views": 1, "parallelism": "single view", "kernel_variant": a.kernel,
+                   "skip_empty": a.skip_empty},
+        "gsamples_per_s": round(n_ref * steps / elapsed / 1e9, 3), "reference_samples_per_step": int(n_ref),
+        "parity_vs_cpu_path": {"max_abs_lsb": int(d.max()), "rmse_normalised": float(np.sqrt(np.mean(d.astype(np.float64) ** 2)) / 255.0)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "march kernel (variant %d)" % a.kernel,
+                     "launches": int(launches), "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
+                     "algorithmic_bytes_per_view": b_alg, "views_per_launch": 1},
+        "cpu_baseline": {"value": round(1.0 / cpu_s, 4), "unit": "views/s", "cores": threads, "kind": "port",
+                         "sample": f"oracle/vr_oracle.c (CPU restatement of raymarcher.wgsl, NOT the wgpu reference on a software adapter, "
+                                   f"which cannot be built here), the whole C1 view, mean of {reps} runs of {cpu_s:.3f} s, OpenMP over "
+                                   f"image rows; {ref['samples']} samples per view",
+                         "gsamples_per_s": round(ref["samples"] / cpu_s / 1e9, 5)},
+    }
+    print(json.dumps(out), flush=True)
+    img.close()
+    rm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,8 +268,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=16, help="views of the export rendered by the CPU baseline (at most)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="stop the CPU baseline after this much CPU-side wall time")
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5", "custom"],
-                    help="BASELINE.json configs[1..3]; C3 is the headline and the default; 'custom' takes --dim/--res/... as given; "
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "custom"],
+                    help="BASELINE.json configs[0..4]; C3 is the headline and the default; 'custom' takes --dim/--res/... as given; "
+                         "C1 = the single-view CPU-path config with the HIP path beside it, see run_c1(); "
                          "C5 = sort-last over a z-slab-partitioned volume (SURVEY 8e), see run_c5()")
     ap.add_argument("--c5-dim", type=int, default=1024, help="C5: volume is dim x dim x 2*dim scalar (SURVEY's 2048 needs 8 GPUs)")
     ap.add_argument("--c5-views", type=int, default=16)
@@ -209,6 +285,8 @@ def main():
     presets = {"C2": dict(dim=256, res=512, xdiv=8, ydiv=9, volume="scalar"),     # 256^3 u8 DAT, 64 views, 512^2
                "C3": dict(dim=512, res=1024, xdiv=16, ydiv=17, volume="rgba"),    # 512^3 f32 RGBA, 256 views, 1024^2
                "C4": dict(dim=1024, res=2048, xdiv=16, ydiv=9, volume="scalar")}  # 1024^3 f32 scalar, 128 views, 2048^2
+    if a.config == "C1":
+        return run_c1(a)
     if a.config == "C5":
         return run_c5(a)
     if a.config in presets:
@@ -345,14 +423,18 @@ def main():
         no_skip = n_views / vd.max_over_ranks(time.perf_counter() - t0, coll_dev)
         rm.set_option(vr.OPT_SKIP_EMPTY, 1)
 
-    # samples actually filtered (N_exec): one pass of this rank's views through the diagnostics build
+    # samples actually filtered (N_exec), how many of them came out with alpha exactly 0 (what finer skipping could
+    # still save) and the chunk statistics: one pass of this rank's views through the diagnostics build
     rm.set_option(vr.OPT_DIAGNOSTICS, 1)
-    n_exec_mine = 0
+    rm.diag_counters()
     for cam_u in my_cams:
         rm.draw(cam_u, banks[0][0])
-        n_exec_mine += int(banks[0][0].executed_samples().sum(dtype=np.uint64))
+    dc = rm.diag_counters()
     rm.set_option(vr.OPT_DIAGNOSTICS, 0)
-    n_exec = vd.sum_over_ranks(n_exec_mine, coll_dev)
+    n_exec = vd.sum_over_ranks(dc["executed"], coll_dev)
+    n_exec_zero = vd.sum_over_ranks(dc["executed_zero_alpha"], coll_dev)
+    chunk_stats = {k: int(vd.sum_over_ranks(dc[k], coll_dev)) for k in ("chunks", "chunks_staged", "chunks_empty", "probes_failed",
+                                                                         "chunks_gathered")}
 
     views_per_s = n_views * a.steps / elapsed
     gsamples = n_ref * a.steps / elapsed / 1e9
@@ -367,19 +449,22 @@ def main():
     # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3 around the process): the figure comes
     # from the committed counter passes of the same workload (profiles/*/traffic.json: 2*FETCH_SIZE + WRITE_SIZE
     # per view, gfx950 correction as in MI355X_MICROARCH.md), scaled to the views of one launch; null if none.
-    traffic = None
+    traffic, secondary = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}" + (":tf" if a.tf else "")
         if key in tj:
             traffic = int(tj[key]["hbm_bytes_per_view"] * B)
+            # SURVEY 8d's secondary ceilings and cache rates of the same kernel on the same workload, from the committed
+            # rocprofv3 PMC passes (formulas: DESIGN.md 4.3; tools/install_profiles.py computes them from profiles/rN/*.txt)
+            secondary = tj[key].get("secondary")
     except (OSError, ValueError, KeyError):
-        traffic = None
+        traffic, secondary = None, None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "march kernel (variant %d)" % a.kernel, "launches": int(launches),
                 "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
-                "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B}
+                "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B, "secondary": secondary}
     # SURVEY.md 8(d) prices the voxels in the INPUT file's format (f32 RGBA = 16 B, f32 scalar = 4 B); the kernel
     # reads the RGBA8 texels the reference's own texture holds (4 B; 1 B for the 1-channel march), so `achieved` and
     # `frac` above use those (the lower figures). The survey-priced pair is carried beside them so either convention
@@ -401,7 +486,8 @@ def main():
                    "volume": [D, D, D], "image": [R, R], "views": n_views, "parallelism": f"view-partitioned x{world}",
                    "kernel_variant": a.kernel, "skip_empty": a.skip_empty},
         "gsamples_per_s": round(gsamples, 3), "reference_samples_per_step": int(n_ref),
-        "executed_samples_per_step": int(n_exec),
+        "executed_samples_per_step": int(n_exec), "executed_empty_samples_per_step": int(n_exec_zero),
+        "chunks_per_step": chunk_stats,
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
         "volume_broadcast_ms": round(bcast_ms, 2), "rccl_ranks": 0 if (rehearse or world == 1) else world, "roofline": roofline,
         "views_per_s_no_skip": None if no_skip is None else round(no_skip, 3),

@@ -287,6 +287,12 @@ VRM_API int vrm_image_read_sample_counts(vrm_image *image, uint32_t *executed);
  * in-box test (wgsl:218-223), hit flag (wgsl:131), 0 -- so tests can check the geometry bit for bit. */
 VRM_API int vrm_image_read_ray_diagnostics(vrm_image *image, float *geom8);
 
+/* Same switch: counters summed over every diagnostics draw since the last reset -- [0] samples filtered and blended (N_exec),
+ * [1] of those, samples whose filtered alpha was exactly 0 (they changed nothing; what finer skipping could still save),
+ * [2] chunk prologues, [3] chunks staged into LDS and sampled, [4] chunks passed over as empty, [5] deep empty-space probes
+ * that found something and were redone as plain chunks, [6] chunks marched with global gathers, [7] 0. */
+VRM_API int vrm_diag_read_counters(vrm_ctx *ctx, uint64_t out[8], int reset);
+
 /* Reference-equivalent sample count (the unit of the Gsamples/s metric): the number of
  * iterations the loop of raymarch() (raymarcher.wgsl:139-187) executes, summed over all rays of the n
  * views at width x height, for the current grid's box -- pure geometry on the reference's dt lattice,

@@ -99,6 +99,7 @@ extern "C" {
     pub fn vrm_image_read_diagnostics(image: *mut vrm_image, rgba_f32: *mut f32, iterations: *mut u32) -> c_int;
     pub fn vrm_image_read_sample_counts(image: *mut vrm_image, executed: *mut u32) -> c_int;
     pub fn vrm_image_read_ray_diagnostics(image: *mut vrm_image, geom8: *mut f32) -> c_int;
+    pub fn vrm_diag_read_counters(ctx: *mut vrm_ctx, out: *mut u64, reset: c_int) -> c_int;
     pub fn vrm_count_reference_samples(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, width: u32, height: u32,
                                        out_total: *mut u64) -> c_int;
     pub fn vrm_last_error() -> *const c_char;

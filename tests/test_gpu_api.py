@@ -368,3 +368,22 @@ def test_export_error_path_joins_and_reports(vr, tmp_path):
     r.export_sphere(4, 4, 2.5, str(good))                          # the context is still usable
     assert len(list(good.glob("*.png"))) == 12
     r.close()
+
+
+def test_netcdf4_hdf5_load(rm1, vr, orc, tmp_path):
+    """open_voxel_grid on a NetCDF-4 = HDF5 container (what the reference's netcdf crate and diffdvr.py write): both dialects of
+    tests/hdf5_builder.py through vrm_load_netcdf, quantised on the GPU like the classic path.  Parity unpinned (see the builder)."""
+    import hdf5_builder as hb
+    rng = np.random.default_rng(11)
+    data = (rng.random((4, 6, 10, 9), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)    # values below 0 and above 1 as well
+    data[2, 3, 4, 5] = np.nan
+    for name, blob in (("old.nc", hb.old_style(data)),
+                       ("new.nc", hb.new_style(data, chunk=(2, 4, 4, 4), skip_chunk=None, unfiltered_chunk=3)[0])):
+        p = os.path.join(tmp_path, name)
+        open(p, "wb").write(blob)
+        rm1.voxel_grid.attenuation = 7.0
+        rm1.voxel_grid.update_voxel_grid_buffer()
+        rm1.load_netcdf(p)
+        g = rm1.voxel_grid
+        assert g.dimensions == (9, 10, 6) and list(g.uniform().buffer) == [1.0] * 4
+        assert np.array_equal(g.download_rgba8(), orc.quantize_netcdf(data))

@@ -1,0 +1,102 @@
+"""NetCDF-4 = HDF5 container of `color(c,z,y,x)` (f-2; host code of libvrm.so, no GPU): the reader of csrc/vrm_hdf5.cpp against
+files assembled byte by byte from the HDF5 File Format Specification (tests/hdf5_builder.py) in the dialects a netCDF-4 file of
+this shape can come in.  PARITY UNPINNED: no netcdf-c / h5py / netCDF4 exists here to write a file to read back, and the
+reference tree holds no data files; what is pinned is the reader against the published format as restated by the builder."""
+import os
+
+import numpy as np
+import pytest
+
+import hdf5_builder as hb
+from volume_renderer_amd import VrmError, netcdf
+
+
+def _data(shape_zyx, seed=0):
+    rng = np.random.default_rng(seed)
+    d = rng.random((4,) + shape_zyx, dtype=np.float32)
+    d[0, 0, 0, 0] = np.float32(1.0)
+    d[3, -1, -1, -1] = np.float32(-0.0)
+    return d
+
+
+def _write(tmp_path, name, blob):
+    p = os.path.join(tmp_path, name)
+    with open(p, "wb") as f:
+        f.write(blob)
+    return p
+
+
+def test_old_style_contiguous(tmp_path):
+    """superblock 0, version-1 object headers, symbol-table root group, contiguous little-endian data (HDF5 1.8 defaults)"""
+    d = _data((5, 6, 7), 1)
+    p = _write(tmp_path, "old.nc", hb.old_style(d))
+    assert netcdf.read_color(p).tobytes() == d.tobytes()
+
+
+@pytest.mark.parametrize("v1_pipeline", [False, True])
+@pytest.mark.parametrize("superblock", [2, 3])
+def test_new_style_chunked_filtered(tmp_path, v1_pipeline, superblock):
+    """superblock 2/3, OHDR headers with continuation blocks, compact links with creation order, big-endian floats, chunks behind a
+    two-level B-tree with shuffle + deflate; edge chunks, a chunk never written (fill value 0), a chunk with deflate masked out"""
+    d = _data((7, 10, 13), 2)
+    blob, expect = hb.new_style(d, chunk=(2, 3, 4, 5), skip_chunk=5, unfiltered_chunk=9, v1_pipeline=v1_pipeline, superblock=superblock)
+    p = _write(tmp_path, "new.nc", blob)
+    got = netcdf.read_color(p)
+    assert got.shape == d.shape
+    assert (expect != d).any()                               # the skipped chunk really is missing
+    assert got.tobytes() == expect.tobytes()
+
+
+def test_chunked_without_filters_and_with_fletcher32(tmp_path):
+    d = _data((4, 4, 6), 3)
+    blob, expect = hb.new_style(d, chunk=(4, 2, 2, 3), skip_chunk=None, unfiltered_chunk=None, filters=())
+    assert netcdf.read_color(_write(tmp_path, "plain.nc", blob)).tobytes() == expect.tobytes() == d.tobytes()
+    blob, expect = hb.new_style(d, chunk=(1, 4, 4, 6), skip_chunk=None, unfiltered_chunk=None, filters=(2, 1, 3))
+    assert netcdf.read_color(_write(tmp_path, "f32.nc", blob)).tobytes() == d.tobytes()
+
+
+@pytest.mark.parametrize("deflate", [False, True])
+def test_layout_v4_single_chunk(tmp_path, deflate):
+    d = _data((3, 5, 4), 4)
+    assert netcdf.read_color(_write(tmp_path, "v4.nc", hb.single_chunk_v4(d, deflate))).tobytes() == d.tobytes()
+
+
+def test_superblock_not_at_offset_zero(tmp_path):
+    """a user block in front: the superblock is searched at 512, 1024, ...; addresses are relative to the base address"""
+    d = _data((2, 3, 4), 5)
+    blob = bytearray(hb.old_style(d))
+    blob[24:32] = (512).to_bytes(8, "little")                # base address field of the version-0 superblock
+    p = _write(tmp_path, "ub.nc", b"\0" * 512 + bytes(blob))
+    assert netcdf.read_color(p).tobytes() == d.tobytes()
+
+
+def test_errors(tmp_path):
+    d = _data((3, 4, 5), 6)
+    good = hb.old_style(d)
+    with pytest.raises(VrmError) as e:                       # truncated in the data
+        netcdf.read_color(_write(tmp_path, "trunc.nc", good[:200]))
+    assert e.value.status == -4
+    with pytest.raises(VrmError) as e:                       # dimension scale x disagrees with the variable's shape
+        netcdf.read_color(_write(tmp_path, "dims.nc", hb.old_style(d, dims_extra={"x": 9})))
+    assert "not color(c,z,y,x)" in str(e.value)
+    with pytest.raises(VrmError) as e:                       # c != 4
+        netcdf.read_color(_write(tmp_path, "c3.nc", hb.old_style(d[:3])))
+    assert "expected 4" in str(e.value)
+    blob = bytearray(good)
+    i = blob.find(b"color\0")
+    blob[i:i + 5] = b"colou"
+    with pytest.raises(VrmError) as e:                       # netcdf.rs:37: expect("Could not find 'color' variable")
+        netcdf.read_color(_write(tmp_path, "nocolor.nc", bytes(blob)))
+    assert "could not find 'color'" in str(e.value)
+    with pytest.raises(VrmError):                            # neither CDF nor HDF5
+        netcdf.read_color(_write(tmp_path, "junk.nc", b"GIF89a" + b"\0" * 600))
+    with pytest.raises(VrmError):                            # half the file is gone: metadata beyond the end
+        netcdf.read_color(_write(tmp_path, "short.nc", good[: len(good) // 2]))
+
+
+def test_lookup3_known_answers():
+    """hashlittle() self-check against the values printed in lookup3.c's driver5() comments"""
+    assert hb.lookup3(b"", 0) == 0xDEADBEEF
+    assert hb.lookup3(b"", 0xDEADBEEF) == 0xBD5B7DDE
+    assert hb.lookup3(b"Four score and seven years ago", 0) == 0x17770551
+    assert hb.lookup3(b"Four score and seven years ago", 1) == 0xCD628161

@@ -86,9 +86,10 @@ def test_errors(tmp_path):
     with pytest.raises(VrmError):
         netcdf.read_color(os.path.join(tmp_path, "missing.nc"))
     hdf = os.path.join(tmp_path, "four.nc")
-    open(hdf, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(VrmError, match="HDF5"):
+    open(hdf, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)       # an HDF5 signature and nothing behind it (tests/test_hdf5_cpu.py
+    with pytest.raises(VrmError) as e:                                 # covers the NetCDF-4 reader proper)
         netcdf.read_color(hdf)
+    assert e.value.status == -4
     junk = os.path.join(tmp_path, "junk.nc")
     open(junk, "wb").write(b"hello world, definitely not netcdf")
     with pytest.raises(VrmError):

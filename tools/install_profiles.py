@@ -9,12 +9,14 @@ import shutil
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+N_SIMD, N_CU = 1024, 256   # MI355X: 256 CUs x 4 SIMDs
 O, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
 for f in ["bench_final_c3.json", "bench_final_c3_under_rocprofv3.json", "bench_final_c3_kernel_stats.csv", "bench_final_c2.json",
-          "bench_final_c4.json", "bench_final_c3_tf.json"]:
-    shutil.copy(os.path.join(O, f), os.path.join(P, f))
+          "bench_final_c4.json", "bench_final_c3_tf.json", "bench_final_c1.json"]:
+    if os.path.exists(os.path.join(O, f)):
+        shutil.copy(os.path.join(O, f), os.path.join(P, f))
 passes = {"final_c3_skip1": ("pmc_final_skip1.txt", 32, "C3:kernel1:skip1"), "final_c3_skip0": ("pmc_final_skip0.txt", 32, "C3:kernel1:skip0"),
           "final_c4_skip1": ("pmc_final_c4_skip1.txt", 16, "C4:kernel1:skip1"), "final_c2_skip1": ("pmc_final_c2_skip1.txt", 32, "C2:kernel1:skip1")}
 tj_path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -30,8 +32,39 @@ for tag, (name, views, key) in passes.items():
     t.setdefault(key, {})["hbm_bytes_per_view"] = int((2 * f + w) * 1024 / views)
     t[key]["source"] = f"profiles/{rnd}/{name} ({views} views per launch)"
     print(key, t[key]["hbm_bytes_per_view"], "B/view, kernel", ms, "ms per launch")
+
+    # SURVEY 8d's secondary ceilings (DESIGN.md 4.3 states the formulas); every input is a per-dispatch mean of that file
+    def c(name_):
+        m = re.search(r"^\s+" + name_ + r"\s+per-dispatch mean = (\S+)", blk, re.M)
+        return float(m.group(1)) if m else None
+    cyc = c("GRBM_GUI_ACTIVE") / 8.0                       # rocprofv3 sums the 8 XCDs
+    sec = {"valu_issue_frac": round(c("SQ_ACTIVE_INST_VALU") * 4.0 / (N_SIMD * cyc), 4),   # quad-cycles of VALU issue / SIMD-cycles
+           "lds_busy_frac": round(c("SQ_LDS_IDX_ACTIVE") / (N_CU * cyc), 4),
+           "lds_bank_conflict_frac": round(c("SQ_LDS_BANK_CONFLICT") / c("SQ_LDS_IDX_ACTIVE"), 4),
+           "l2_hit_rate": round(c("TCC_HIT_sum") / (c("TCC_HIT_sum") + c("TCC_MISS_sum")), 4),
+           "mall_hit_rate": None,
+           "mall_note": "rocprofv3 on gfx950 lists no Infinity-Cache hit/miss counter (rocprofv3 -L); TCC_EA0_RDREQ_DRAM classifies a "
+                        "fabric read by destination, not by where it was served",
+           "wait_frac": round(c("SQ_WAIT_INST_ANY") / c("SQ_WAVE_CYCLES"), 4),
+           "valu_insts_per_launch": c("SQ_INSTS_VALU"), "salu_insts_per_launch": c("SQ_INSTS_SALU"),
+           "kernel_clock_ghz": round(cyc / (float(ms) * 1e-3) / 1e9, 3)}
+    if c("TCC_EA0_RDREQ_sum"):
+        sec["ea_read_dram_dest_frac"] = round(c("TCC_EA0_RDREQ_DRAM_sum") / c("TCC_EA0_RDREQ_sum"), 4)
+    m = re.search(r"COUNTERS views=(\d+) n_ref=(\d+) executed=(\d+) executed_zero_alpha=(\d+) chunks=(\d+) chunks_staged=(\d+) "
+                  r"chunks_empty=(\d+) probes_failed=(\d+)", s)
+    if m:
+        n_exec = int(m.group(3))
+        sec["valu_insts_per_wave_sample"] = round(c("SQ_INSTS_VALU") / (n_exec / 64.0), 2)
+        sec["executed_over_reference_samples"] = round(n_exec / int(m.group(2)), 4)
+        sec["executed_zero_alpha_frac"] = round(int(m.group(4)) / n_exec, 4)
+        sec["chunk_prologues_per_view"] = int(m.group(5)) // int(m.group(1))
+        sec["chunks_staged_per_view"] = int(m.group(6)) // int(m.group(1))
+    t[key]["secondary"] = sec
+    print("   secondary:", {k: v for k, v in sec.items() if k != "mall_note"})
 json.dump(t, open(tj_path, "w"), indent=1)
 for f in ["bench_final_c3.json", "bench_final_c3_under_rocprofv3.json", "bench_final_c2.json", "bench_final_c4.json", "bench_final_c3_tf.json"]:
+    if not os.path.exists(os.path.join(P, f)):
+        continue
     d = json.load(open(os.path.join(P, f)))
     print(f, d["value"], "views/s", d["gsamples_per_s"], "Gsamples/s, launch", d["roofline"]["avg_launch_ms"], "ms, frac", d["roofline"]["frac"],
           "N_exec/N_ref", round(d.get("executed_samples_per_step", 0) / d["reference_samples_per_step"], 3))

@@ -15,6 +15,11 @@ def short(name):
 
 def main():
     root = sys.argv[1]
+    tl = os.path.join(root, "trace.log")
+    if os.path.exists(tl):
+        for line in open(tl):
+            if line.startswith("COUNTERS") or line.startswith("kernel "):
+                print("== workload: " + line.strip())
     for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)):
         print(f"== kernel stats ({os.path.relpath(f, root)})")
         for row in csv.DictReader(open(f)):

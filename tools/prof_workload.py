@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--ydiv", type=int, default=17)
     ap.add_argument("--ix", type=int, default=-1, help="only the views of this azimuth index")
     ap.add_argument("--all", action="store_true", help="every view of the sphere, in launches of --views")
+    ap.add_argument("--count-exec", action="store_true", help="also print the executed-sample and chunk counters of the launch "
+                    "(one extra pass through the diagnostics build)")
     a = ap.parse_args()
     D, R = a.dim, a.res
     rm = vr.RayMarcher(0, R, R)
@@ -93,6 +95,14 @@ def main():
         ms, n = rm.profile_read()
         print(f"kernel {a.kernel} skip {a.skip}: {len(cams)} views {R}^2 of {D}^3: {ms:.2f} ms => {ms / len(cams):.3f} ms/view, "
               f"{n_ref / ms / 1e6:.1f} Gsamples/s (ref-equivalent)", flush=True)
+    if a.count_exec:
+        rm.set_option(vr.OPT_PROFILE, 0)
+        rm.set_option(vr.OPT_DIAGNOSTICS, 1)
+        rm.diag_counters()
+        for c in cams:
+            rm.draw(c, imgs[0])
+        dc = rm.diag_counters()
+        print(f"COUNTERS views={len(cams)} n_ref={n_ref} " + " ".join(f"{k}={v}" for k, v in dc.items()), flush=True)
 
 
 if __name__ == "__main__":

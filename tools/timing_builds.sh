@@ -10,7 +10,7 @@ make -s
 for f in NO_STAGE NO_STEPS; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc \
       -fvisibility=hidden -DVRM_TIMING_$f -c vrm_kernels.hip -o /tmp/vrm_kernels_$f.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vrm_kernels_$f.o vrm_api.o vrm_host.o vrm_eval.o vrm_netcdf.o -shared \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vrm_kernels_$f.o vrm_api.o vrm_host.o vrm_eval.o vrm_netcdf.o vrm_hdf5.o -shared \
       -Wl,-rpath,/opt/rocm/lib -lz -lpthread -o ../timing_$f.so
   rm -f /tmp/vrm_kernels_$f.o
 done

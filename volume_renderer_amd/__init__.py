@@ -323,6 +323,13 @@ class RayMarcher:
         _ffi.check(_ffi.lib().vrm_count_reference_samples(self._h, cams, n, int(width), int(height), ctypes.byref(total)))
         return total.value
 
+    def diag_counters(self, reset=True):
+        """Counters of the diagnostics draws since the last reset (vrm_diag_read_counters) as a dict."""
+        out = (ctypes.c_uint64 * 8)()
+        _ffi.check(_ffi.lib().vrm_diag_read_counters(self._h, out, 1 if reset else 0))
+        names = ["executed", "executed_zero_alpha", "chunks", "chunks_staged", "chunks_empty", "probes_failed", "chunks_gathered"]
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
     def synchronize(self):
         _ffi.check(_ffi.lib().vrm_synchronize(self._h))
 

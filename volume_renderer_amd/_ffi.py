@@ -88,6 +88,7 @@ SYMBOLS = {
     "vrm_image_read_diagnostics": (ctypes.c_int, [_vp, _f32p, _u32p]),
     "vrm_image_read_sample_counts": (ctypes.c_int, [_vp, _u32p]),
     "vrm_image_read_ray_diagnostics": (ctypes.c_int, [_vp, _f32p]),
+    "vrm_diag_read_counters": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "vrm_count_reference_samples": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
     "vrm_load_netcdf": (ctypes.c_int, [_vp, ctypes.c_char_p]),

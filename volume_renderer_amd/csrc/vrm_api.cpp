@@ -220,6 +220,7 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
         if ((rc = vrm_check_hip(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate"))) break;
         if ((rc = scratch_init(ctx->device, &ctx->scratch))) break; // this device's copy of the static descriptor scratch
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
+        if ((rc = vrm_check_hip(hipMemsetAsync(ctx->flag_dev, 0, 256, ctx->stream), "hipMemsetAsync"))) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
                                 "hipHostMalloc")))
@@ -705,6 +706,7 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, w, h, targets[0]->pitch);
     p.views = dev_views;
+    p.diag_counters = diag ? reinterpret_cast<unsigned long long *>(ctx->flag_dev + 16) : nullptr; // bytes 64..127 of the 256-byte scratch
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->opt_profile && !use_static) {
@@ -836,6 +838,17 @@ extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_unifor
     HIP_TRY(hipMemcpyAsync(&host, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out_total = host;
+    return VRM_OK;
+}
+
+extern "C" int vrm_diag_read_counters(vrm_ctx *ctx, uint64_t out[8], int reset)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(out != nullptr, "null argument");
+    HIP_TRY(hipMemcpyAsync(out, ctx->flag_dev + 16, 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIP_TRY(hipMemsetAsync(ctx->flag_dev + 16, 0, 64, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VRM_OK;
 }
 

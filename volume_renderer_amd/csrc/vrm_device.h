@@ -67,6 +67,10 @@ struct VrmMarchParams {
     uint32_t use_tf;
     uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 8 texels of depth)
     int32_t packed_alpha; // 1-channel march staged from the packed alpha bricks (default) or, 0, from the RGBA8 bricks
+    // diagnostics build only (else nullptr): 8 counters the waves add to -- filtered samples, of those with alpha exactly 0,
+    // chunk prologues, chunks staged, chunks passed over as empty, deep empty-space probes that found something, chunks
+    // marched with global gathers (vrm_diag_read_counters)
+    unsigned long long *diag_counters;
 };
 
 // launchers implemented in vrm_kernels.hip

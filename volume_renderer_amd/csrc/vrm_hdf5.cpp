@@ -1,0 +1,551 @@
+// vrm_hdf5.cpp -- the NetCDF-4 container of the reference's own volume files.
+//
+// `netcdf::create` / `netcdf::open` in loaders/netcdf.rs:10,35 and `Dataset(..., format='NETCDF4_CLASSIC')` in
+// scripts/diffdvr.py:278 produce NetCDF-4 files, i.e. HDF5 containers: the variable `color(c,z,y,x)` is an HDF5 dataset
+// named "color" in the root group, the dimensions c, z, y, x are (dimension-scale) datasets beside it.  netcdf-c and the
+// HDF5 library are dependencies of the reference that are neither in its tree nor in this image, so this is a reader for
+// the subset of the published HDF5 File Format Specification (version 3.0) that such files use, restated from the
+// specification:
+//   * superblock versions 0, 1 (symbol-table root) and 2, 3 (root object header address);
+//   * object headers version 1 and version 2 ("OHDR"), with continuation blocks ("OCHK" for version 2);
+//   * groups as a symbol table (B-tree version 1 "TREE" of "SNOD" nodes + local "HEAP") and as compact link messages
+//     (what netcdf-c's creation-order tracking produces for a handful of objects); dense link storage (fractal heap)
+//     is recognised and refused;
+//   * the dataset's dataspace (versions 1, 2), datatype (IEEE f32, little or big endian) and data layout message
+//     version 3 -- contiguous, or chunked through a version-1 chunk B-tree -- and version 4 contiguous / single-chunk;
+//   * the filter pipeline with deflate (zlib), shuffle and fletcher32 (checksum not verified), the filters netCDF-4 offers.
+// PARITY UNPINNED: no file written by netcdf-c / h5py / netCDF4 exists in this environment to read back; the tests
+// assemble files byte by byte from the same specification (tests/hdf5_builder.py).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vrm_internal.h"
+
+int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *out, size_t capacity_floats);
+
+namespace {
+
+const uint64_t UNDEF = ~0ull;
+
+struct Fail {
+    std::string msg;
+};
+
+struct H5 {
+    FILE *f;
+    const char *path;
+    uint64_t base = 0, file_size = 0;
+    int so = 8, sl = 8; // size of offsets / lengths
+
+    [[noreturn]] void fail(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+    {
+        char buf[400];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        throw Fail{std::string(path) + ": " + buf};
+    }
+    void read(uint64_t addr, void *dst, size_t n)
+    {
+        if (addr == UNDEF || addr + base + n > file_size || addr + base + n < addr) fail("read of %zu bytes at %llu beyond the end of the file", n, (unsigned long long)addr);
+        if (fseeko(f, (off_t)(addr + base), SEEK_SET) != 0 || fread(dst, 1, n, f) != n) fail("cannot read %zu bytes at %llu", n, (unsigned long long)addr);
+    }
+    std::vector<uint8_t> block(uint64_t addr, size_t n)
+    {
+        if (n > ((size_t)1 << 28)) fail("metadata block of %zu bytes is not plausible", n);
+        std::vector<uint8_t> b(n);
+        read(addr, b.data(), n);
+        return b;
+    }
+};
+
+// little-endian field reader over a metadata block
+struct Cur {
+    H5 &h;
+    const uint8_t *p, *end;
+    Cur(H5 &h_, const uint8_t *b, size_t n) : h(h_), p(b), end(b + n) {}
+    void need(size_t n) { if ((size_t)(end - p) < n) h.fail("truncated metadata"); }
+    uint64_t u(int n)
+    {
+        need((size_t)n);
+        uint64_t v = 0;
+        for (int i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i);
+        p += n;
+        return v;
+    }
+    uint64_t off() { const uint64_t v = u(h.so); return (h.so < 8 && v == (1ull << (8 * h.so)) - 1) ? UNDEF : v; }
+    uint64_t len() { return u(h.sl); }
+    void skip(size_t n) { need(n); p += n; }
+    size_t left() const { return (size_t)(end - p); }
+};
+
+struct Message {
+    uint16_t type;
+    uint8_t flags;
+    std::vector<uint8_t> data;
+};
+
+// every message of an object header (version 1 or 2), continuation blocks followed
+std::vector<Message> object_header(H5 &h, uint64_t addr)
+{
+    std::vector<Message> out;
+    uint8_t sig[4];
+    h.read(addr, sig, 4);
+    struct Span { uint64_t addr, size; };
+    std::vector<Span> todo;
+    bool v2 = memcmp(sig, "OHDR", 4) == 0;
+    bool track_order = false;
+    if (v2) {
+        auto b = h.block(addr, 64);
+        Cur c(h, b.data(), b.size());
+        c.skip(4);
+        if (c.u(1) != 2) h.fail("object header version is not 2");
+        const uint8_t flags = (uint8_t)c.u(1);
+        if (flags & 0x20) c.skip(16);
+        if (flags & 0x10) c.skip(4);
+        const uint64_t sz = c.u(1 << (flags & 3));
+        track_order = flags & 0x04;
+        todo.push_back({addr + (uint64_t)(c.p - b.data()), sz});
+    } else {
+        auto b = h.block(addr, 16);
+        Cur c(h, b.data(), b.size());
+        if (c.u(1) != 1) h.fail("object header at %llu is neither version 1 nor version 2", (unsigned long long)addr);
+        c.skip(1);
+        c.u(2); // number of messages: the sizes bound the walk
+        c.skip(4);
+        const uint64_t sz = c.u(4);
+        todo.push_back({addr + 16, sz});
+    }
+    for (size_t t = 0; t < todo.size(); ++t) {
+        if (todo.size() > 4096) h.fail("object header continuation chain is not plausible");
+        uint64_t a = todo[t].addr, n = todo[t].size;
+        if (t > 0 && v2) { // "OCHK" + messages + checksum
+            uint8_t s2[4];
+            h.read(a, s2, 4);
+            if (memcmp(s2, "OCHK", 4) != 0) h.fail("bad continuation block signature");
+            a += 4;
+            n -= 8;
+        }
+        auto b = h.block(a, (size_t)n);
+        Cur c(h, b.data(), b.size());
+        const size_t hdr = v2 ? (size_t)(4 + (track_order ? 2 : 0)) : 8;
+        while (c.left() >= hdr) {
+            Message m;
+            uint64_t sz;
+            if (v2) {
+                m.type = (uint16_t)c.u(1);
+                sz = c.u(2);
+                m.flags = (uint8_t)c.u(1);
+                if (track_order) c.skip(2);
+            } else {
+                m.type = (uint16_t)c.u(2);
+                sz = c.u(2);
+                m.flags = (uint8_t)c.u(1);
+                c.skip(3);
+            }
+            if (sz > c.left()) { if (v2) break; h.fail("object header message overruns its block"); } // (v2: the gap before the checksum)
+            m.data.assign(c.p, c.p + sz);
+            c.skip((size_t)sz);
+            if (m.type == 0x0010) { // continuation
+                Cur cc(h, m.data.data(), m.data.size());
+                const uint64_t ca = cc.off(), cl = cc.len();
+                todo.push_back({ca, cl});
+            } else if (m.type != 0) {
+                out.push_back(std::move(m));
+            }
+        }
+    }
+    return out;
+}
+
+// name -> object header address of every link of a group
+void group_links(H5 &h, const std::vector<Message> &msgs, std::vector<std::pair<std::string, uint64_t>> &links)
+{
+    for (const Message &m : msgs) {
+        if (m.type == 0x0011) { // symbol table: B-tree v1 + local heap
+            Cur c(h, m.data.data(), m.data.size());
+            const uint64_t btree = c.off(), heap = c.off();
+            auto hb = h.block(heap, (size_t)(8 + 2 * h.sl + h.so));
+            if (memcmp(hb.data(), "HEAP", 4) != 0) h.fail("bad local heap signature");
+            Cur hc(h, hb.data() + 8, hb.size() - 8);
+            const uint64_t hsize = hc.len();
+            hc.len();
+            const uint64_t hdata = hc.off();
+            auto names = h.block(hdata, (size_t)hsize);
+            std::vector<uint64_t> nodes{btree};
+            size_t visited = 0;
+            while (!nodes.empty()) {
+                if (++visited > 100000) h.fail("group B-tree is not plausible");
+                const uint64_t a = nodes.back();
+                nodes.pop_back();
+                uint8_t sig[4];
+                h.read(a, sig, 4);
+                if (memcmp(sig, "TREE", 4) == 0) {
+                    auto nb = h.block(a, (size_t)(8 + 2 * h.so));
+                    Cur nc(h, nb.data() + 4, nb.size() - 4);
+                    if (nc.u(1) != 0) h.fail("group B-tree node has the wrong type");
+                    nc.u(1);
+                    const uint64_t used = nc.u(2);
+                    auto body = h.block(a + 8 + 2 * (uint64_t)h.so, (size_t)((used + 1) * h.sl + used * h.so));
+                    Cur bc(h, body.data(), body.size());
+                    for (uint64_t i = 0; i < used; ++i) {
+                        bc.len(); // key
+                        nodes.push_back(bc.off());
+                    }
+                } else if (memcmp(sig, "SNOD", 4) == 0) {
+                    auto nb = h.block(a, 8);
+                    Cur nc(h, nb.data() + 4, 4);
+                    nc.skip(2);
+                    const uint64_t n = nc.u(2);
+                    const size_t esz = (size_t)(2 * h.so + 24);
+                    auto body = h.block(a + 8, (size_t)n * esz);
+                    for (uint64_t i = 0; i < n; ++i) {
+                        Cur ec(h, body.data() + i * esz, esz);
+                        const uint64_t name_off = ec.off(), ohdr = ec.off();
+                        if (name_off >= names.size()) h.fail("link name outside the local heap");
+                        const char *s = reinterpret_cast<const char *>(names.data() + name_off);
+                        links.emplace_back(std::string(s, strnlen(s, names.size() - (size_t)name_off)), ohdr);
+                    }
+                } else {
+                    h.fail("unexpected node in a group B-tree");
+                }
+            }
+        } else if (m.type == 0x0006) { // link message
+            Cur c(h, m.data.data(), m.data.size());
+            if (c.u(1) != 1) h.fail("link message version is not 1");
+            const uint8_t fl = (uint8_t)c.u(1);
+            uint8_t ltype = 0;
+            if (fl & 0x08) ltype = (uint8_t)c.u(1);
+            if (fl & 0x04) c.skip(8);
+            if (fl & 0x10) c.skip(1);
+            const uint64_t nlen = c.u(1 << (fl & 3));
+            c.need((size_t)nlen);
+            std::string name(reinterpret_cast<const char *>(c.p), (size_t)nlen);
+            c.skip((size_t)nlen);
+            if (ltype == 0) links.emplace_back(name, c.off()); // hard link; soft / external links are not followed
+        } else if (m.type == 0x0002) { // link info: dense storage?
+            Cur c(h, m.data.data(), m.data.size());
+            c.u(1);
+            const uint8_t fl = (uint8_t)c.u(1);
+            if (fl & 1) c.skip(8);
+            if (c.off() != UNDEF)
+                h.fail("the root group stores its links densely (fractal heap: more than 8 objects); only compact link messages and "
+                       "symbol-table groups are read");
+        }
+    }
+}
+
+struct Dataset {
+    std::vector<uint64_t> dims;
+    bool big_endian = false;
+    int layout = -1; // 1 contiguous, 2 chunked (B-tree v1), 3 single chunk
+    uint64_t addr = UNDEF, size = 0;
+    std::vector<uint64_t> chunk; // chunk dims (elements), rank entries
+    struct Filter { uint16_t id; };
+    std::vector<Filter> filters;
+    uint32_t single_filter_mask = 0;
+};
+
+Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
+{
+    Dataset d;
+    bool have_space = false, have_type = false;
+    for (const Message &m : msgs) {
+        Cur c(h, m.data.data(), m.data.size());
+        if (m.type == 0x0001) { // dataspace
+            const uint64_t ver = c.u(1), rank = c.u(1), fl = c.u(1);
+            if (ver == 1) c.skip(5);
+            else if (ver == 2) c.skip(1);
+            else h.fail("dataspace message version %llu", (unsigned long long)ver);
+            if (rank > 32) h.fail("dataspace rank %llu", (unsigned long long)rank);
+            for (uint64_t i = 0; i < rank; ++i) d.dims.push_back(c.len());
+            (void)fl;
+            have_space = true;
+        } else if (m.type == 0x0003) { // datatype
+            const uint64_t cv = c.u(1), b0 = c.u(1);
+            c.skip(2);
+            const uint64_t size = c.u(4);
+            if ((cv & 0x0f) != 1 || size != 4) h.fail("variable 'color' is not a 4-byte floating-point dataset (class %llu, size %llu)", (unsigned long long)(cv & 0x0f), (unsigned long long)size);
+            d.big_endian = b0 & 1;
+            c.u(2);
+            const uint64_t prec = c.u(2), eloc = c.u(1), esz = c.u(1), mloc = c.u(1), msz = c.u(1), bias = c.u(4);
+            if (prec != 32 || eloc != 23 || esz != 8 || mloc != 0 || msz != 23 || bias != 127) h.fail("variable 'color' is not IEEE binary32");
+            have_type = true;
+        } else if (m.type == 0x0008) { // data layout
+            const uint64_t ver = c.u(1);
+            if (ver == 3) {
+                const uint64_t cls = c.u(1);
+                if (cls == 1) {
+                    d.layout = 1;
+                    d.addr = c.off();
+                    d.size = c.len();
+                } else if (cls == 2) {
+                    d.layout = 2;
+                    const uint64_t nd = c.u(1);
+                    d.addr = c.off();
+                    for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u(4));
+                    if (c.u(4) != 4) h.fail("chunk element size is not 4");
+                } else {
+                    h.fail("compact dataset storage is not read");
+                }
+            } else if (ver == 4) {
+                const uint64_t cls = c.u(1);
+                if (cls == 1) {
+                    d.layout = 1;
+                    d.addr = c.off();
+                    d.size = c.len();
+                } else if (cls == 2) {
+                    const uint64_t fl = c.u(1), nd = c.u(1), enc = c.u(1);
+                    for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u((int)enc));
+                    c.u((int)enc);
+                    const uint64_t idx = c.u(1);
+                    if (idx != 1) h.fail("version-4 chunk index type %llu is not read (only contiguous, version-1 B-tree and single-chunk layouts)", (unsigned long long)idx);
+                    d.layout = 3;
+                    if (fl & 2) { d.size = c.len(); d.single_filter_mask = (uint32_t)c.u(4); }
+                    d.addr = c.off();
+                } else {
+                    h.fail("data layout class %llu is not read", (unsigned long long)cls);
+                }
+            } else {
+                h.fail("data layout message version %llu is not read (HDF5 older than 1.6.3)", (unsigned long long)ver);
+            }
+        } else if (m.type == 0x000B) { // filter pipeline
+            const uint64_t ver = c.u(1), n = c.u(1);
+            if (ver == 1) c.skip(6);
+            else if (ver != 2) h.fail("filter pipeline version %llu", (unsigned long long)ver);
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint16_t id = (uint16_t)c.u(2);
+                uint64_t nlen = 0;
+                if (ver == 1 || id >= 256) nlen = c.u(2);
+                c.u(2);
+                const uint64_t nv = c.u(2);
+                if (ver == 1) c.skip((size_t)((nlen + 7) & ~7ull));
+                else c.skip((size_t)nlen);
+                c.skip((size_t)nv * 4);
+                if (ver == 1 && (nv & 1)) c.skip(4);
+                if (id != 1 && id != 2 && id != 3) h.fail("filter %u is not supported (deflate, shuffle, fletcher32 are)", id);
+                d.filters.push_back({id});
+            }
+        }
+    }
+    if (!have_space || !have_type || d.layout < 0) h.fail("object 'color' is not a dataset (dataspace, datatype or layout message missing)");
+    return d;
+}
+
+// one stored chunk -> `raw` (chunk_bytes) through the inverse filter pipeline
+void decode_chunk(H5 &h, const Dataset &d, uint64_t addr, uint64_t stored, uint32_t mask, size_t chunk_bytes, std::vector<uint8_t> &raw,
+                  std::vector<uint8_t> &tmp)
+{
+    if (stored > ((uint64_t)1 << 31)) h.fail("chunk of %llu bytes is not plausible", (unsigned long long)stored);
+    tmp.resize((size_t)stored);
+    h.read(addr, tmp.data(), (size_t)stored);
+    size_t cur = (size_t)stored;
+    for (size_t i = d.filters.size(); i-- > 0;) {
+        if (mask & (1u << i)) continue;
+        const uint16_t id = d.filters[i].id;
+        if (id == 3) { // fletcher32: the checksum trails the data
+            if (cur < 4) h.fail("chunk too short for its checksum");
+            cur -= 4;
+        } else if (id == 1) { // deflate
+            raw.resize(chunk_bytes);
+            uLongf n = (uLongf)chunk_bytes;
+            if (uncompress(raw.data(), &n, tmp.data(), (uLong)cur) != Z_OK) h.fail("a chunk does not inflate");
+            cur = (size_t)n;
+            tmp.assign(raw.begin(), raw.begin() + (long)cur);
+        } else if (id == 2) { // shuffle, element size 4
+            raw.resize(cur);
+            const size_t n = cur / 4;
+            for (size_t e = 0; e < n; ++e)
+                for (size_t b = 0; b < 4; ++b) raw[4 * e + b] = tmp[b * n + e];
+            for (size_t r = 4 * n; r < cur; ++r) raw[r] = tmp[r];
+            tmp.assign(raw.begin(), raw.begin() + (long)cur);
+        }
+    }
+    if (cur != chunk_bytes) h.fail("a chunk decodes to %zu bytes, expected %zu", cur, chunk_bytes);
+    raw.assign(tmp.begin(), tmp.begin() + (long)cur);
+}
+
+void copy_chunk(const Dataset &d, const std::vector<uint64_t> &origin, const uint8_t *raw, float *out)
+{
+    // 4-d chunk at `origin` (elements) into the row-major (c, z, y, x) array; edge chunks are stored whole, clipped here
+    const uint64_t *D = d.dims.data(), *C = d.chunk.data();
+    if (origin[0] >= D[0] || origin[1] >= D[1] || origin[2] >= D[2] || origin[3] >= D[3]) return;
+    const uint64_t n3 = (origin[3] + C[3] <= D[3]) ? C[3] : D[3] - origin[3];
+    for (uint64_t a = 0; a < C[0] && origin[0] + a < D[0]; ++a)
+        for (uint64_t b = 0; b < C[1] && origin[1] + b < D[1]; ++b)
+            for (uint64_t c = 0; c < C[2] && origin[2] + c < D[2]; ++c) {
+                const uint8_t *src = raw + 4 * (((a * C[1] + b) * C[2] + c) * C[3]);
+                float *dst = out + (((origin[0] + a) * D[1] + origin[1] + b) * D[2] + origin[2] + c) * D[3] + origin[3];
+                memcpy(dst, src, (size_t)n3 * 4);
+            }
+}
+
+void read_chunked(H5 &h, const Dataset &d, float *out)
+{
+    if (d.chunk.size() != 4) h.fail("chunk rank %zu, expected 4", d.chunk.size());
+    size_t chunk_bytes = 4;
+    for (uint64_t c : d.chunk) {
+        if (c == 0 || c > ((uint64_t)1 << 31)) h.fail("bad chunk dimension");
+        if (chunk_bytes > ((size_t)1 << 32) / (size_t)c) h.fail("chunk too large");
+        chunk_bytes *= (size_t)c;
+    }
+    std::vector<uint8_t> raw, tmp;
+    if (d.layout == 3) {
+        if (d.addr == UNDEF) return; // never written: fill value 0
+        decode_chunk(h, d, d.addr, d.filters.empty() ? chunk_bytes : d.size, d.single_filter_mask, chunk_bytes, raw, tmp);
+        copy_chunk(d, {0, 0, 0, 0}, raw.data(), out);
+        return;
+    }
+    if (d.addr == UNDEF) return;
+    std::vector<uint64_t> nodes{d.addr};
+    size_t visited = 0;
+    const size_t key = 8 + 8 * 5; // chunk size, filter mask, 5 offsets of 8 bytes (rank + 1)
+    while (!nodes.empty()) {
+        if (++visited > 50000000) h.fail("chunk B-tree is not plausible");
+        const uint64_t a = nodes.back();
+        nodes.pop_back();
+        auto nb = h.block(a, (size_t)(8 + 2 * h.so));
+        if (memcmp(nb.data(), "TREE", 4) != 0) h.fail("bad chunk B-tree node signature");
+        Cur nc(h, nb.data() + 4, nb.size() - 4);
+        if (nc.u(1) != 1) h.fail("chunk B-tree node has the wrong type");
+        const uint64_t level = nc.u(1), used = nc.u(2);
+        auto body = h.block(a + 8 + 2 * (uint64_t)h.so, (size_t)(used * (key + h.so) + key));
+        Cur bc(h, body.data(), body.size());
+        for (uint64_t i = 0; i < used; ++i) {
+            const uint64_t stored = bc.u(4);
+            const uint32_t mask = (uint32_t)bc.u(4);
+            std::vector<uint64_t> origin(4);
+            for (int k = 0; k < 4; ++k) origin[(size_t)k] = bc.u(8);
+            bc.u(8);
+            const uint64_t child = bc.off();
+            if (level > 0) {
+                nodes.push_back(child);
+            } else {
+                decode_chunk(h, d, child, stored, mask, chunk_bytes, raw, tmp);
+                copy_chunk(d, origin, raw.data(), out);
+            }
+        }
+    }
+}
+
+} // namespace
+
+// `f` is open on a file that starts with the HDF5 signature.  With out == NULL a size query.
+int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *out, size_t capacity_floats)
+{
+    try {
+        H5 h{f, path};
+        if (fseeko(f, 0, SEEK_END) != 0) h.fail("cannot seek");
+        h.file_size = (uint64_t)ftello(f);
+        // the superblock sits at 0, 512, 1024, ... (netCDF-4 files: 0)
+        uint64_t sb = UNDEF;
+        static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+        for (uint64_t a = 0; a + 8 <= h.file_size && a <= ((uint64_t)1 << 30); a = a ? 2 * a : 512) {
+            uint8_t s[8];
+            h.read(a, s, 8);
+            if (memcmp(s, sig, 8) == 0) { sb = a; break; }
+        }
+        if (sb == UNDEF) h.fail("neither a NetCDF classic file (CDF\\001/\\002/\\005) nor a NetCDF-4 / HDF5 file (no superblock signature)");
+        auto b = h.block(sb, (size_t)std::min<uint64_t>(h.file_size - sb, 128));
+        Cur c(h, b.data(), b.size());
+        c.skip(8);
+        const uint64_t ver = c.u(1);
+        uint64_t root = UNDEF;
+        std::vector<Message> root_msgs;
+        if (ver <= 1) {
+            c.skip(4); // free-space version, root group version, reserved, shared header version
+            h.so = (int)c.u(1);
+            h.sl = (int)c.u(1);
+            c.skip(1);
+            c.skip(4); // group leaf / internal node K
+            c.skip(4); // consistency flags
+            if (ver == 1) c.skip(4);
+            if ((h.so != 4 && h.so != 8) || (h.sl != 4 && h.sl != 8)) h.fail("offsets of %d and lengths of %d bytes are not read", h.so, h.sl);
+            const uint64_t base = c.off();
+            c.off();
+            c.off();
+            c.off();
+            h.base = base == UNDEF ? 0 : base;
+            c.off(); // root symbol table entry: link name offset
+            root = c.off();
+        } else if (ver <= 3) {
+            h.so = (int)c.u(1);
+            h.sl = (int)c.u(1);
+            c.skip(1);
+            if ((h.so != 4 && h.so != 8) || (h.sl != 4 && h.sl != 8)) h.fail("offsets of %d and lengths of %d bytes are not read", h.so, h.sl);
+            const uint64_t base = c.off();
+            c.off();
+            c.off();
+            root = c.off();
+            h.base = base == UNDEF ? 0 : base;
+        } else {
+            h.fail("superblock version %llu is not read", (unsigned long long)ver);
+        }
+        root_msgs = object_header(h, root);
+        std::vector<std::pair<std::string, uint64_t>> links;
+        group_links(h, root_msgs, links);
+        uint64_t color = UNDEF;
+        uint64_t named[3] = {UNDEF, UNDEF, UNDEF};
+        for (auto &l : links) {
+            if (l.first == "color") color = l.second;
+            if (l.first == "x") named[0] = l.second;
+            if (l.first == "y") named[1] = l.second;
+            if (l.first == "z") named[2] = l.second;
+        }
+        if (color == UNDEF) h.fail("could not find 'color' variable"); // netcdf.rs:37 expect()
+        const Dataset d = parse_dataset(h, object_header(h, color));
+        if (d.dims.size() != 4) h.fail("variable 'color' has %zu dimensions, expected (c, z, y, x)", d.dims.size());
+        if (d.dims[0] != 4) h.fail("dimension c is %llu, expected 4", (unsigned long long)d.dims[0]);
+        for (int i = 1; i < 4; ++i)
+            if (d.dims[(size_t)i] == 0 || d.dims[(size_t)i] > 0xffffffffull) h.fail("dimension %d of 'color' is %llu", i, (unsigned long long)d.dims[(size_t)i]);
+        // netcdf.rs:39-41 takes the lengths from the dimensions named x, y, z: where those dimension scales exist they must agree
+        for (int i = 0; i < 3; ++i)
+            if (named[i] != UNDEF) {
+                try {
+                    const Dataset s = parse_dataset(h, object_header(h, named[i]));
+                    if (s.dims.size() == 1 && s.dims[0] != d.dims[(size_t)(3 - i)])
+                        h.fail("dimension '%c' has length %llu but 'color' has %llu there: not color(c,z,y,x)", "xyz"[i],
+                               (unsigned long long)s.dims[0], (unsigned long long)d.dims[(size_t)(3 - i)]);
+                } catch (const Fail &e) {
+                    if (e.msg.find("not color(c,z,y,x)") != std::string::npos) throw;
+                    // a dimension scale of a type this reader does not parse: its length is not needed
+                }
+            }
+        *z = (uint32_t)d.dims[1];
+        *y = (uint32_t)d.dims[2];
+        *x = (uint32_t)d.dims[3];
+        if (!out) return VRM_OK;
+        const uint64_t n = 4ull * d.dims[1] * d.dims[2] * d.dims[3];
+        if (capacity_floats < n) {
+            vrm_set_error("%s holds %llu floats, buffer holds %zu", path, (unsigned long long)n, capacity_floats);
+            return VRM_ERR_INVALID;
+        }
+        if (d.layout == 1) {
+            if (d.addr == UNDEF) {
+                memset(out, 0, (size_t)n * 4); // never written: the fill value
+            } else {
+                if (d.size < n * 4) h.fail("contiguous storage of %llu bytes is shorter than the %llu the dimensions need", (unsigned long long)d.size, (unsigned long long)(n * 4));
+                const size_t step = (size_t)1 << 26;
+                for (uint64_t done = 0; done < n * 4; done += step) h.read(d.addr + done, reinterpret_cast<uint8_t *>(out) + done, (size_t)std::min<uint64_t>(step, n * 4 - done));
+            }
+        } else {
+            memset(out, 0, (size_t)n * 4); // chunks that were never written read as the fill value
+            read_chunked(h, d, out);
+        }
+        if (d.big_endian) {
+            uint32_t *w = reinterpret_cast<uint32_t *>(out);
+            for (uint64_t i = 0; i < n; ++i) w[i] = __builtin_bswap32(w[i]);
+        }
+        return VRM_OK;
+    } catch (const Fail &e) {
+        vrm_set_error("%s", e.msg.c_str());
+        return VRM_ERR_IO;
+    }
+}

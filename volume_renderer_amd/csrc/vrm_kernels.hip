@@ -127,7 +127,7 @@ struct Accum {
 // + Beer-Lambert opacity (wgsl:150) + front-to-back blend (wgsl:158-159).  Returns alpha >= 1 (wgsl:176).
 template <bool ALPHA_ONLY, bool USE_TF>
 __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
-                                      Accum &acc)
+                                      Accum &acc, float *a_out = nullptr)
 {
     // Byte k of an RGBA8 word read through SDWA is the f32 denormal k * 2^-149: one instruction gives the difference
     // of two texels' channels, exact, and an FMA with the 2^127-scaled weight brings it back into the normal range
@@ -147,6 +147,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         return __builtin_fmaf(wz, c1 - c0, c0);
     };
     const float a255 = tri(std::integral_constant<int, 3>{}) * T22;
+    if (a_out) *a_out = a255;
     // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a255 * kexp), a255 = filtered alpha in 0..255
     const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
     const float om = 1.0f - acc.alpha;
@@ -180,7 +181,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
 // texel x+1 in byte 1 (rows: y0z0, y1z0, y0z1, y1z1).  Same arithmetic on the same values as shade<true, USE_TF>.
 template <bool USE_TF>
 __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
-                                             Accum &acc)
+                                             Accum &acc, float *a_out = nullptr)
 {
     const float wxs = wx * 0x1p127f;
     auto xlerp = [&](uint32_t t) -> float {
@@ -192,6 +193,7 @@ __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, floa
     const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
     const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
     const float a255 = __builtin_fmaf(wz, c1 - c0, c0) * T22;
+    if (a_out) *a_out = a255;
     const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
     const float om = 1.0f - acc.alpha;
     const float wgt = om * alpha_src;
@@ -449,7 +451,7 @@ __device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_m
 }
 
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED>
-__global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
+__global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel(const VrmMarchParams P)
 {
     // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
     // four x-adjacent texels instead of one RGBA8 texel: a quarter of the staging bytes and of the tile's x extent.
@@ -482,6 +484,8 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 
     Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t iters = 0, n_inside = 0, n_exec = 0;
+    // diagnostics build: per-lane count of filtered samples whose alpha came out exactly 0, and per-wave chunk statistics
+    uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0;
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
@@ -549,7 +553,9 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         // ---- this chunk: steps per lane and the texel-space bounding box of everything they touch ----
         float ua[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+        // (the formula the samples are filtered at: the box below then holds their texels whatever the camera distance --
+        // the exact position ro + rd*dt, rounded at the magnitude of ro, differs from it by up to 0.06 texel at radius 1000)
+        for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(dt, rs[a], bla[a]);
         if (!DIAG && g.slab) {
             // Slab-partitioned volume: this rank marches the whole volume's lattice but blends only its slab's samples.
             // (The diagnostics build walks every step so that its per-ray counts stay those of the unpartitioned march.)
@@ -573,7 +579,7 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
 #ifdef VRM_AB_ADAPT_KK
-        int kk = kk_start;
+        int kk = lvl > 0 ? (int)P.chunk_steps << lvl : kk_start;
 #else
         int kk = (int)P.chunk_steps << lvl; // chunk length: the steps of the rear-most lane
 #endif
@@ -607,6 +613,35 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #endif
             return margin_ok;
         };
+        // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
+        // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
+        // the dt lattice has to advance.  A look-up in level lvl of the occupancy pyramid over the cells the box [ilo, ihi]
+        // overlaps (up to two per lane); a box of more cells counts as not empty.
+        auto box_is_empty = [&]() __attribute__((always_inline)) -> bool {
+            const int sh = 2 + lvl; // cells of level lvl are 4 << lvl texels wide
+            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
+            const int c0x = max(ilo[0], 0) >> sh, c0y = max(ilo[1], 0) >> sh, c0z = max(ilo[2], 0) >> sh;
+            const int ncx = (min(ihi[0], mxx) >> sh) - c0x + 1, ncy = (min(ihi[1], mxy) >> sh) - c0y + 1,
+                      ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
+            const int ncxy = ncx * ncy, nc = ncxy * ncz;
+            if (nc > 128) return false;
+            const uint32_t rnd = (1u << lvl) - 1u;
+            const size_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
+            const uint8_t *occl = g.occ + g.occ_off[lvl];
+            const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
+            bool occ = false;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int c = (int)lane + 64 * r;
+                if (c < nc) {
+                    const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
+                    const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
+                    occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * od0 + (size_t)(c0x + cx)] != 0;
+                }
+            }
+            return __builtin_amdgcn_ballot_w64(occ) == 0ull;
+        };
+        bool empty = false;
         for (;;) {
             // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
             const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
@@ -628,47 +663,23 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
         }
 #ifdef VRM_AB_ADAPT_KK
-        if (fits) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
+        if (fits && !empty) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
 #endif
-        if (!fits && !none && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
-            kk = 8;
-            n_lane = active ? min(8, steps_left) : 0;
-            // the box above is that of the ONE step that did not fit; the emptiness test below must cover all 8
-            (void)chunk_box(n_lane, ilo, ihi);
-        }
-
-        // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
-        // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
-        // the dt lattice has to advance.  First a look-up in the 4x4x4-texel-cell max-alpha grid, later the staged texels.
-        bool empty = none;
-        if (SKIP && !none) {
-            const int sh = 2 + lvl; // cells of level lvl are 4 << lvl texels wide
-            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const int c0x = max(ilo[0], 0) >> sh, c0y = max(ilo[1], 0) >> sh, c0z = max(ilo[2], 0) >> sh;
-            const int ncx = (min(ihi[0], mxx) >> sh) - c0x + 1, ncy = (min(ihi[1], mxy) >> sh) - c0y + 1,
-                      ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
-            const int ncxy = ncx * ncy, nc = ncxy * ncz;
-            if (nc <= 128) { // up to two cells per lane
-                const uint32_t rnd = (1u << lvl) - 1u;
-                const size_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
-                const uint8_t *occl = g.occ + g.occ_off[lvl];
-                const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
-                bool occ = false;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int c = (int)lane + 64 * r;
-                    if (c < nc) {
-                        const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
-                        const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
-                        occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * od0 + (size_t)(c0x + cx)] != 0;
-                    }
-                }
-                empty = __builtin_amdgcn_ballot_w64(occ) == 0ull;
+        if (none) empty = true;
+        else {
+            if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
+                kk = 8;
+                n_lane = active ? min(8, steps_left) : 0;
+                // the box above is that of the ONE step that did not fit; the emptiness test must cover all 8
+                (void)chunk_box(n_lane, ilo, ihi);
             }
+            if (SKIP) empty = box_is_empty();
         }
+        if (DIAG) ++st_chunks;
         if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
             lvl = 0;
             lvl_run = 0;
+            if (DIAG) ++st_probe_fail;
             continue; // nothing was advanced
         }
 
@@ -750,6 +761,11 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
 #ifdef VRM_TIMING_NO_STEPS // timing build: prologue + staging + dt advance, no samples
         empty = true;
 #endif
+        if (DIAG) {
+            if (empty) ++st_empty;
+            else if (fits) ++st_staged;
+            else ++st_fallback;
+        }
         if (empty) {
             // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
             if (!DIAG) advance_exact(dt, active, ray.t_max, n_lane); // (the diagnostics build counts in-box samples per step)
@@ -828,14 +844,18 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
                                 w[1] = __builtin_amdgcn_alignbyte(ld(a1 + 4), ld(a1), sh);
                                 w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
                                 w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
-                                done = shade_packed<USE_TF>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                                float a255 = 1.0f;
+                                done = shade_packed<USE_TF>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             } else {
                                 uint32_t c[8];
                                 c[0] = ld(a0); c[1] = ld(a0 + 4);
                                 c[2] = ld(a1); c[3] = ld(a1 + 4);
                                 c[4] = ld(a2); c[5] = ld(a2 + 4);
                                 c[6] = ld(a3); c[7] = ld(a3 + 4);
-                                done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                                float a255 = 1.0f;
+                                done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             }
                         }
                         if (!done) {
@@ -883,6 +903,23 @@ __global__ void __launch_bounds__(64) march_lds_kernel(const VrmMarchParams P)
     }
     finish_colour<ALPHA_ONLY, USE_TF>(acc);
     if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside, n_exec);
+    if (DIAG && P.diag_counters) { // vrm_diag_read_counters: one atomic per counter and wave
+        unsigned long long e = n_exec, z = n_zero;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            e += __shfl_down(e, off, 64);
+            z += __shfl_down(z, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&P.diag_counters[0], e);
+            atomicAdd(&P.diag_counters[1], z);
+            atomicAdd(&P.diag_counters[2], (unsigned long long)st_chunks);
+            atomicAdd(&P.diag_counters[3], (unsigned long long)st_staged);
+            atomicAdd(&P.diag_counters[4], (unsigned long long)st_empty);
+            atomicAdd(&P.diag_counters[5], (unsigned long long)st_probe_fail);
+            atomicAdd(&P.diag_counters[6], (unsigned long long)st_fallback);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

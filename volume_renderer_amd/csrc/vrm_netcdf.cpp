@@ -1,19 +1,25 @@
 // vrm_netcdf.cpp -- the NetCDF interchange of the path: loaders/netcdf.rs:8-69 and
 // scripts/diffdvr.py:276-287 exchange volumes as one variable `color(c,z,y,x)` of f32 with c = 4.
 //
-// What is implemented is the netCDF CLASSIC container (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), restated
-// from the published file-format specification (NetCDF Users Guide, "File Format Specification": big-endian header of
-// dimension / attribute / variable lists, fixed-size variable data at `begin`).  The reference's own files are
-// NetCDF-4, i.e. HDF5 containers (netcdf::create in the Rust crate, format='NETCDF4_CLASSIC' in diffdvr.py); an HDF5
-// reader is not part of this build: such a file is recognised by its signature and rejected with a message that
-// names the conversion (`nccopy -k cdf5 in.nc out.nc`).  The data model (names, dimension order, f32, value range)
-// is the reference's either way.  Host code only; the device side is vrm_grid_upload_f32 / vrm_grid_download_rgba8.
+// This file: the netCDF CLASSIC container (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), restated from the
+// published file-format specification (NetCDF Users Guide, "File Format Specification": big-endian header of
+// dimension / attribute / variable lists, fixed-size variable data at `begin`), reader and writer.  The reference's own
+// files are NetCDF-4, i.e. HDF5 containers (netcdf::create in the Rust crate, format='NETCDF4_CLASSIC' in diffdvr.py):
+// those are recognised by their signature and read by vrm_hdf5.cpp.  What this library WRITES is the classic container,
+// which netcdf-c -- and so the reference's netcdf::open -- reads transparently.  The data model (names, dimension order,
+// f32, value range) is the reference's either way.  Host code only; the device side is vrm_grid_upload_f32 /
+// vrm_grid_download_rgba8.
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "vrm_internal.h"
+
+// vrm_hdf5.cpp: `color(c,z,y,x)` from a NetCDF-4 / HDF5 container
+int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *out, size_t capacity_floats);
 
 #define REQUIRE_IO(cond, ...)                             \
     do {                                                  \
@@ -92,11 +98,6 @@ int read_header(FILE *f, const char *path, Header *h)
 {
     uint8_t magic[8] = {0};
     REQUIRE_IO(fread(magic, 1, 4, f) == 4, "%s: too short for a NetCDF file", path);
-    if (!memcmp(magic, "\x89HDF", 4)) {
-        vrm_set_error("%s is a NetCDF-4/HDF5 file; this build reads the classic container only (CDF-1/2/5): convert it with "
-                      "`nccopy -k cdf5 %s classic.nc`", path, path);
-        return VRM_ERR_IO;
-    }
     REQUIRE_IO(magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F' && (magic[3] == 1 || magic[3] == 2 || magic[3] == 5),
                "%s is not a NetCDF classic file (no CDF\\001, CDF\\002 or CDF\\005 signature)", path);
     Reader r{f, magic[3]};
@@ -173,6 +174,7 @@ struct Writer {
 
 extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *color_czyx, size_t capacity_floats)
 {
+    return vrm_guard("vrm_netcdf_read_color", VRM_ERR_IO, [&]() -> int {
     if (!path || !x || !y || !z) {
         vrm_set_error("null argument");
         return VRM_ERR_INVALID;
@@ -180,12 +182,22 @@ extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y,
     File fl;
     fl.f = fopen(path, "rb");
     REQUIRE_IO(fl.f != nullptr, "cannot open %s", path);
+    uint8_t sig[4] = {0, 0, 0, 0};
+    const size_t got = fread(sig, 1, 4, fl.f);
+    // a NetCDF-4 file is an HDF5 container (its superblock may also sit at 512, 1024, ...: anything that is not CDF goes there)
+    if (got == 4 && memcmp(sig, "CDF", 3) != 0) return vrm_hdf5_read_color(fl.f, path, x, y, z, color_czyx, capacity_floats);
+    rewind(fl.f);
     Header h;
     const int rc = read_header(fl.f, path, &h);
     if (rc) return rc;
     *x = (uint32_t)h.x;
     *y = (uint32_t)h.y;
     *z = (uint32_t)h.z;
+    struct stat st;
+    REQUIRE_IO(fstat(fileno(fl.f), &st) == 0 && (uint64_t)st.st_size >= h.begin &&
+                   ((uint64_t)st.st_size - h.begin) / 16 >= h.x * h.y * h.z,   // (x, y, z < 2^32 each: the product of two fits 64 bits)
+               "%s: data of 'color' is truncated: the header promises color(4,%llu,%llu,%llu) but the file has only %lld bytes", path, (unsigned long long)h.z,
+               (unsigned long long)h.y, (unsigned long long)h.x, (long long)st.st_size);
     if (!color_czyx) return VRM_OK; // size query
     const size_t n = (size_t)4 * h.x * h.y * h.z;
     if (capacity_floats < n) {
@@ -201,10 +213,12 @@ extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y,
         for (size_t i = 0; i < k; ++i) w[i] = bswap32(w[i]); // XDR: big-endian IEEE
     }
     return VRM_OK;
+    });
 }
 
 extern "C" int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx)
 {
+    return vrm_guard("vrm_netcdf_write_color", VRM_ERR_IO, [&]() -> int {
     if (!path || !color_czyx || x == 0 || y == 0 || z == 0) {
         vrm_set_error("null argument or empty volume");
         return VRM_ERR_INVALID;
@@ -246,11 +260,13 @@ extern "C" int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, 
         REQUIRE_IO(fwrite(buf.data(), 4, k, fl.f) == k, "%s: write failed", path);
     }
     return VRM_OK;
+    });
 }
 
 // loaders::netcdf::open_voxel_grid (netcdf.rs:34-69)
 extern "C" int vrm_load_netcdf(vrm_ctx *ctx, const char *path)
 {
+    return vrm_guard("vrm_load_netcdf", VRM_ERR_IO, [&]() -> int {
     if (!ctx) {
         vrm_set_error("null context");
         return VRM_ERR_INVALID;
@@ -258,17 +274,23 @@ extern "C" int vrm_load_netcdf(vrm_ctx *ctx, const char *path)
     uint32_t x = 0, y = 0, z = 0;
     int rc = vrm_netcdf_read_color(path, &x, &y, &z, nullptr, 0);
     if (rc) return rc;
+    // the header must not size an allocation the file cannot fill (deflate expands at most ~1032:1)
+    struct stat st;
+    REQUIRE_IO(stat(path, &st) == 0 && (double)x * y * z * 16.0 <= (double)st.st_size * 1040.0 + 65536.0,
+               "%s: the header promises color(4,%u,%u,%u), more than its %lld bytes can hold", path, z, y, x, (long long)st.st_size);
     std::vector<float> data((size_t)4 * x * y * z);
     rc = vrm_netcdf_read_color(path, &x, &y, &z, data.data(), data.size());
     if (rc) return rc;
     rc = vrm_grid_resize(ctx, x, y, z);             // VoxelGrid::new (netcdf.rs:47)
     if (rc) return rc;
     return vrm_grid_upload_f32(ctx, data.data(), 4); // (v * 255.0) as u8 per channel (netcdf.rs:54-57), on the GPU
+    });
 }
 
 // loaders::netcdf::write_voxel_grid (netcdf.rs:8-31)
 extern "C" int vrm_write_netcdf(vrm_ctx *ctx, const char *path)
 {
+    return vrm_guard("vrm_write_netcdf", VRM_ERR_IO, [&]() -> int {
     if (!ctx) {
         vrm_set_error("null context");
         return VRM_ERR_INVALID;
@@ -285,4 +307,5 @@ extern "C" int vrm_write_netcdf(vrm_ctx *ctx, const char *path)
     for (size_t i = 0; i < n; ++i)
         for (int c = 0; c < 4; ++c) data[(size_t)c * n + i] = (float)vox[4 * i + c] / 255.0f; // netcdf.rs:23
     return vrm_netcdf_write_color(path, ctx->dim[0], ctx->dim[1], ctx->dim[2], data.data());
+    });
 }

@@ -1,6 +1,6 @@
-"""NetCDF interchange of the path: `color(c,z,y,x)` f32 in a netCDF classic container, through
-libvrm.so (vrm_netcdf_read_color / vrm_netcdf_write_color; host code, no GPU needed).  The reference's own files are
-NetCDF-4/HDF5 (loaders/netcdf.rs:10, scripts/diffdvr.py:278); those are refused with a message naming the conversion."""
+"""NetCDF interchange of the path: `color(c,z,y,x)` f32 through libvrm.so (vrm_netcdf_read_color /
+vrm_netcdf_write_color; host code, no GPU needed).  Read: the netCDF classic containers (CDF-1/2/5) and NetCDF-4 = HDF5, what
+the reference's own netcdf crate and scripts/diffdvr.py:278 write (csrc/vrm_hdf5.cpp).  Written: classic, which netcdf-c reads."""
 import ctypes
 import os
 
