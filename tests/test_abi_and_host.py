@@ -115,3 +115,40 @@ def test_rust_sys_crate_declares_every_symbol():
     src = open(os.path.join(ROOT, "rust", "vrm-sys", "src", "lib.rs")).read()
     declared = set(re.findall(r"pub fn (vrm_\w+)\(", src))
     assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
+
+
+def test_rust_patch_keeps_reference_signatures():
+    """rust/patch (f-3) cannot be compiled here; what can be checked is textual: the replacement files declare the public
+    interface State calls with the reference's own signatures (ray_marcher/mod.rs:22,26,113; voxel/grid.rs:44,202,214,240,244),
+    every vrm_sys:: symbol they use exists in the ABI, and -- where /root/reference is present -- each signature line is found
+    verbatim (modulo whitespace and an underscore on unused arguments) in the file it replaces."""
+    import re
+    from conftest import ROOT
+    from volume_renderer_amd import _ffi
+    norm = lambda t: re.sub(r"\s+", "", t).replace("_device", "device").replace("_queue", "queue").replace("_camera_bind_group", "camera_bind_group")
+    mod = open(os.path.join(ROOT, "rust", "patch", "ray_marcher_mod.rs")).read()
+    grid = open(os.path.join(ROOT, "rust", "patch", "voxel_grid.rs")).read()
+    want_mod = ["pub fn new(device: &Device, queue: &Queue, config: &SurfaceConfiguration, camera_bind_group: Rc<BindGroup>) -> Self",
+                "pub fn draw(&self, device: &Device, view: &TextureView) -> CommandBuffer", "pub voxel_grid: VoxelGrid"]
+    want_grid = ["pub fn new(dimensions: UVec3, device: &Device, queue: &Queue) -> Self", "pub fn set_color(&mut self, position: UVec3, color: [u8; 4])",
+                 "pub fn update_buffer(&self, queue: &Queue)", "pub fn update_voxel_grid_buffer(&mut self, queue: &Queue)",
+                 "pub fn update_transfer_function_buffer(&mut self, queue: &Queue)", "pub dimensions: UVec3", "pub attenuation: f32",
+                 "pub transfer_function_colors: RaymarchTransferFunctionColors", "impl Index<UVec3> for VoxelGrid", "impl IndexMut<UVec3> for VoxelGrid"]
+    for sig in want_mod:
+        assert norm(sig) in norm(mod), sig
+    for sig in want_grid:
+        assert norm(sig) in norm(grid), sig
+    used = set(re.findall(r"vrm_sys::(vrm_\w+)\(", mod + grid))
+    assert used and used <= set(_ffi.SYMBOLS), used - set(_ffi.SYMBOLS)
+    ref = "/root/reference/src"
+    if os.path.isdir(ref):                                     # not on the GPU box
+        ref_mod = norm(open(os.path.join(ref, "ray_marcher", "mod.rs")).read())
+        ref_grid = norm(open(os.path.join(ref, "voxel", "grid.rs")).read())
+        for sig in want_mod:
+            assert norm(sig) in ref_mod, sig
+        for sig in want_grid:
+            assert norm(sig) in ref_grid, sig
+        # state.rs needs nothing else from the two types: every member it touches is in the lists above
+        state = open(os.path.join(ref, "state.rs")).read()
+        touched = set(re.findall(r"ray_marcher\.voxel_grid\.(\w+)", state)) | set(re.findall(r"ray_marcher\.(\w+)\(", state))
+        assert touched <= {"attenuation", "transfer_function_colors", "update_voxel_grid_buffer", "update_transfer_function_buffer", "draw"}, touched
