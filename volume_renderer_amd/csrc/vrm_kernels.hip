@@ -462,14 +462,29 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
     constexpr int PX_MAX = 64; // one staging instruction holds at least one whole row
     __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
     const VrmGridDev &g = P.grid;
+#ifdef VRM_AB_VIEW_INTERLEAVE
+    // A/B experiment (DESIGN.md 4.3, C4 staging): VRM_AB_VIEW_INTERLEAVE consecutive views of the launch advance through
+    // the image together (dispatch order: tile slot, then view within the group) instead of one view after the other
+    const uint32_t per_view = gridDim.x >> 3;                        // tile slots of one view on one XCD
+    const uint32_t q_ = (blockIdx.x >> 3) + per_view * blockIdx.y;   // this workgroup's position in its XCD's dispatch order
+    const uint32_t grp_ = q_ / (VRM_AB_VIEW_INTERLEAVE * per_view), r_ = q_ - grp_ * (VRM_AB_VIEW_INTERLEAVE * per_view);
+    const uint32_t view = grp_ * VRM_AB_VIEW_INTERLEAVE + r_ % VRM_AB_VIEW_INTERLEAVE;
+    if (view >= gridDim.y) return;
+    const uint32_t slot_ab = r_ / VRM_AB_VIEW_INTERLEAVE;
+#else
     const uint32_t view = blockIdx.y;
+#endif
     // Tile order.  The image is cut into 64x64-pixel super-blocks (8x8 wave tiles).  Workgroup b runs on the
     // XCD group b % 8 (hardware round-robin); that group owns the super-blocks on the diagonals
     // (sbx + sby) % 8 == b % 8 and walks through them one after the other.  So the ~320 waves an XCD has in
     // flight cover a few compact image patches (=> a compact part of the volume in its L2), while every XCD
     // gets the same mix of centre (long rays) and border (misses) super-blocks: the in-order dispatcher
     // stalls on the slowest XCD, so balance matters more than anything else here.
+#ifdef VRM_AB_VIEW_INTERLEAVE
+    const uint32_t xcd = blockIdx.x & 7u, slot = slot_ab;
+#else
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+#endif
     const uint32_t j = slot >> 6, within = slot & 63u;
     const uint32_t per_row = P.sblocks_x >> 3;             // sblocks_x is padded to a multiple of 8
     const uint32_t sby = j / per_row, m = j - sby * per_row;
