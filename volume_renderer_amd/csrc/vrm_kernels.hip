@@ -125,15 +125,16 @@ struct Accum {
 
 // Trilinear filter of the 8 corner texels (c[z][y][x] as RGBA8 words) + transfer function (wgsl:145-147)
 // + Beer-Lambert opacity (wgsl:150) + front-to-back blend (wgsl:158-159).  Returns alpha >= 1 (wgsl:176).
-template <bool ALPHA_ONLY, bool USE_TF>
-__device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
+// Filter arithmetic runs in units of 2^-22 texel levels (see byte_scaled): `a22` below is the filtered alpha in those units,
+// kexp22 = kexp * 2^22 / 255... folded by the caller so that a22 * kexp22 = -a * step * attenuation * log2(e).
+template <bool ALPHA_ONLY, bool USE_TF, bool ERT>
+__device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp22, const VrmMarchParams &P,
                                       Accum &acc, float *a_out = nullptr)
 {
     // Byte k of an RGBA8 word read through SDWA is the f32 denormal k * 2^-149: one instruction gives the difference
     // of two texels' channels, exact, and an FMA with the 2^127-scaled weight brings it back into the normal range
     // (tools/probes/valu_probe.hip: values exact, the FMA runs at full rate with a denormal operand).  Per x-lerp
-    // that is sub_sdwa + mul_sdwa + fma instead of two conversions, a subtraction and an FMA.  The filter works in
-    // units of 2^-22 texel levels; T22 undoes it.
+    // that is sub_sdwa + mul_sdwa + fma instead of two conversions, a subtraction and an FMA.
     const float wxs = wx * 0x1p127f;
     auto tri = [&](auto kc) -> float {
         constexpr int k = decltype(kc)::value;
@@ -146,15 +147,15 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
         return __builtin_fmaf(wz, c1 - c0, c0);
     };
-    const float a255 = tri(std::integral_constant<int, 3>{}) * T22;
-    if (a_out) *a_out = a255;
-    // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a255 * kexp), a255 = filtered alpha in 0..255
-    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
+    const float a22 = tri(std::integral_constant<int, 3>{});
+    if (a_out) *a_out = a22;
+    // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a22 * kexp22)
+    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a22 * kexp22);
     const float om = 1.0f - acc.alpha;
     const float w = om * alpha_src;
     if (USE_TF) {
         // piecewise-linear in a with the breakpoint at 0.5: A->B below, B->C above
-        const float a = a255 * (1.0f / 255.0f);
+        const float a = a22 * (T22 * (1.0f / 255.0f));
         const bool hi = a >= 0.5f;
         const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
         const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
@@ -164,23 +165,24 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         acc.cg = __builtin_fmaf(w, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
         acc.cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
     } else if (ALPHA_ONLY) {
-        acc.cr = __builtin_fmaf(w, a255, acc.cr); // r == g == b == a for scalar volumes
-    } else if (__builtin_amdgcn_ballot_w64(a255 != 0.0f) != 0ull) {
+        acc.cr = __builtin_fmaf(w, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
+    } else if (__builtin_amdgcn_ballot_w64(a22 != 0.0f) != 0ull) {
         // a == 0 => alpha_src = 0 => w = 0 => the colour terms add exactly 0: filter r,g,b only when some
         // lane of the wave has a non-zero alpha (wave-uniform branch, three quarters of the filter work)
-        // (accumulated in units of 2^-22 texel levels, finish_colour() rescales)
         acc.cr = __builtin_fmaf(w, tri(std::integral_constant<int, 0>{}), acc.cr);
         acc.cg = __builtin_fmaf(w, tri(std::integral_constant<int, 1>{}), acc.cg);
         acc.cb = __builtin_fmaf(w, tri(std::integral_constant<int, 2>{}), acc.cb);
     }
     acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
-    return acc.alpha >= 1.0f;
+    // wgsl:176.  Without ERT the launcher has established that no sample can reach alpha_src >= 0.5 (attenuation < 690), and
+    // then alpha never rounds up to 1.0: the test is dead and left out.
+    return ERT ? acc.alpha >= 1.0f : false;
 }
 
 // The 1-channel march from the packed alpha copy (VrmGridDev::abricks): w[i] holds texel x of row i in byte 0 and
 // texel x+1 in byte 1 (rows: y0z0, y1z0, y0z1, y1z1).  Same arithmetic on the same values as shade<true, USE_TF>.
-template <bool USE_TF>
-__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp, const VrmMarchParams &P,
+template <bool USE_TF, bool ERT>
+__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp22, const VrmMarchParams &P,
                                              Accum &acc, float *a_out = nullptr)
 {
     const float wxs = wx * 0x1p127f;
@@ -192,13 +194,13 @@ __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, floa
     const float c00 = xlerp(w[0]), c10 = xlerp(w[1]), c01 = xlerp(w[2]), c11 = xlerp(w[3]);
     const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
     const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
-    const float a255 = __builtin_fmaf(wz, c1 - c0, c0) * T22;
-    if (a_out) *a_out = a255;
-    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a255 * kexp);
+    const float a22 = __builtin_fmaf(wz, c1 - c0, c0);
+    if (a_out) *a_out = a22;
+    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a22 * kexp22);
     const float om = 1.0f - acc.alpha;
     const float wgt = om * alpha_src;
     if (USE_TF) {
-        const float a = a255 * (1.0f / 255.0f);
+        const float a = a22 * (T22 * (1.0f / 255.0f));
         const bool hi = a >= 0.5f;
         const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
         const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
@@ -208,23 +210,22 @@ __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, floa
         acc.cg = __builtin_fmaf(wgt, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
         acc.cb = __builtin_fmaf(wgt, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
     } else {
-        acc.cr = __builtin_fmaf(wgt, a255, acc.cr); // r == g == b == a for scalar volumes
+        acc.cr = __builtin_fmaf(wgt, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
     }
     acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
-    return acc.alpha >= 1.0f;
+    return ERT ? acc.alpha >= 1.0f : false;
 }
 
 template <bool ALPHA_ONLY, bool USE_TF>
 __device__ __forceinline__ void finish_colour(Accum &acc)
 {
     if (!USE_TF) {
+        const float s = T22 * (1.0f / 255.0f); // colours were accumulated in units of 2^-22 texel levels
+        acc.cr *= s;
         if (ALPHA_ONLY) {
-            acc.cr *= 1.0f / 255.0f;
             acc.cg = acc.cr;
             acc.cb = acc.cr;
         } else {
-            const float s = T22 * (1.0f / 255.0f); // colours were accumulated in units of 2^-22 texel levels
-            acc.cr *= s;
             acc.cg *= s;
             acc.cb *= s;
         }
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
     Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t iters = 0, n_inside = 0;
     if (ray.hit) {
-        const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
+        const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22;
         float dt = ray.t_min;
         for (int i = 0; i < VRM_MAX_STEP_AMOUNT; ++i) {
             ++iters;
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
                 const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                 uint32_t c[8];
                 fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                if (shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc)) break; // wgsl:176-178
+                if (shade<ALPHA_ONLY, USE_TF, true>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc)) break; // wgsl:176-178
             }
             dt += VRM_STEP_SIZE;          // wgsl:181, running f32 sum
             if (dt >= ray.t_max) break;   // wgsl:184-186
@@ -450,7 +451,7 @@ __device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_m
     }
 }
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT>
 __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel(const VrmMarchParams P)
 {
     // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
     uint32_t iters = 0, n_inside = 0, n_exec = 0;
     // diagnostics build: per-lane count of filtered samples whose alpha came out exactly 0, and per-wave chunk statistics
     uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0;
-    const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f);
+    const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22; // per 2^-22 texel level
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
 
@@ -860,7 +861,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
                                 w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
                                 w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
                                 float a255 = 1.0f;
-                                done = shade_packed<USE_TF>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                done = shade_packed<USE_TF, ERT>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             } else {
                                 uint32_t c[8];
@@ -869,15 +870,13 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
                                 c[4] = ld(a2); c[5] = ld(a2 + 4);
                                 c[6] = ld(a3); c[7] = ld(a3 + 4);
                                 float a255 = 1.0f;
-                                done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             }
                         }
-                        if (!done) {
-                            dt += VRM_STEP_SIZE;
-                            done = dt >= ray.t_max;
-                        }
-                        active = !done;
+                        // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
+                        dt += VRM_STEP_SIZE;
+                        active = !(done || dt >= ray.t_max);
                     }
                 }
             };
@@ -903,13 +902,11 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
                         fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                        done = shade<ALPHA_ONLY, USE_TF>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
                     }
-                    if (!done) {
-                        dt += VRM_STEP_SIZE;
-                        done = dt >= ray.t_max;
-                    }
-                    active = !done;
+                    // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
+                    dt += VRM_STEP_SIZE;
+                    active = !(done || dt >= ray.t_max);
                 }
             }
         }
@@ -1286,7 +1283,7 @@ inline uint32_t stream_blocks(size_t n)
     return (uint32_t)(b < cap ? (b ? b : 1) : cap);
 }
 
-template <bool A, bool T, bool D>
+template <bool A, bool T, bool D, bool E>
 void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
 {
     if (variant == 0) {
@@ -1297,40 +1294,43 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         // texels a ray advances per step (the step is 0.001 world units whatever the resolution, wgsl:126)
         float tps = 0.0f;
         for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
-#define VRM_LDS(CAPV, DEPTH)                                                                                   \
-    do {                                                                                                       \
-        /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                   \
+#define VRM_LDS(CAPV, DEPTH, PK)                                                                                  \
+    do {                                                                                                          \
+        /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                      \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, false>), grid, block, 0, stream, p); \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, false>), grid, block, 0, stream, p);     \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E>), grid, block, 0, stream, p);       \
     } while (0)
-        // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU)
-        // 10 KB is the measured optimum for 256^3 .. 1024^3 volumes (tools/prof_workload.py --all); the others are
-        // kept selectable (VRM_OPT_KERNEL) for A/B runs
-        switch (variant) {
-        case 2: VRM_LDS(2048, 6.0f); break;  //  8 KB -> 20 waves/CU by LDS (the ~92 VGPRs allow 20)
-        case 3: VRM_LDS(2304, 8.0f); break;  //  9 KB -> 17 waves/CU
-        case 4: VRM_LDS(3072, 9.0f); break;  // 12 KB -> 13 waves/CU
-        case 5: VRM_LDS(4096, 16.0f); break; // 16 KB -> 10 waves/CU
-        default:
+        // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU).  10 KB (16 waves per
+        // CU) is the measured optimum for 256^3 .. 1024^3 volumes; variant 2 keeps the 8 KB tile (20 waves per CU, 5 per
+        // SIMD) selectable for A/B runs (VRM_OPT_KERNEL): more resident waves do not pay for the shallower chunks.
+        if (variant == 2) {
+            VRM_LDS(2048, 6.0f, false);
+        } else {
             // 1-channel march (scalar volume or transfer function): staged from the packed alpha bricks -- a quarter of
-            // the bytes and of the tile's x extent, so 12 texels of depth fit where the RGBA tile holds 8.  Measured
-            // against the RGBA source (tools/prof_workload.py --packed 0/1): C4 2.10 -> 1.50 ms/view, C3 with the
-            // transfer function 0.42 -> 0.36, C2 0.136 -> 0.128; smaller tiles (more waves per CU) lose.
+            // the bytes and of the tile's x extent, so 12 texels of depth fit where the RGBA tile holds 8.
             // VRM_OPT_PACKED_ALPHA = 0 keeps the RGBA source.
+            bool done = false;
             if constexpr (A) {
                 if (p.grid.abricks != nullptr && p.packed_alpha != 0) {
-                    if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf(12.0f / tps + 0.5f), 2.0f), 64.0f);
-                    if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, 2560, true>), grid, block, 0, stream, p);
-                    else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, 2560, true>), grid, block, 0, stream, p);
-                    break;
+                    VRM_LDS(2560, 12.0f, true);
+                    done = true;
                 }
             }
-            VRM_LDS(2560, 8.0f); // 10 KB -> 16 waves/CU (variant 1, the default)
-            break;
+            if (!done) VRM_LDS(2560, 8.0f, false); // 10 KB -> 16 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
+}
+
+template <bool A, bool T, bool D>
+void launch_ert(const VrmMarchParams &p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
+{
+    // The early exit `alpha >= 1.0` (wgsl:176) can only fire if some sample has alpha_src >= 0.5, i.e.
+    // a * attenuation * 0.001 >= ln 2 with a <= 1: attenuation >= 693 (the GUI's range ends at 100).
+    // Below 690 the kernels are instantiated without the test; anything else (NaN included) keeps it.
+    if (p.attenuation < 690.0f) launch_variant<A, T, D, false>(p, n_views, variant, skip, stream);
+    else launch_variant<A, T, D, true>(p, n_views, variant, skip, stream);
 }
 
 } // namespace
@@ -1397,13 +1397,13 @@ hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int varia
     const bool tf = p.use_tf != 0;
     const bool alpha_only = p.grid.scalar != 0;
     if (diagnostics) {
-        if (tf) launch_variant<true, true, true>(p, n_views, variant, skip, stream);
-        else if (alpha_only) launch_variant<true, false, true>(p, n_views, variant, skip, stream);
-        else launch_variant<false, false, true>(p, n_views, variant, skip, stream);
+        if (tf) launch_ert<true, true, true>(p, n_views, variant, skip, stream);
+        else if (alpha_only) launch_ert<true, false, true>(p, n_views, variant, skip, stream);
+        else launch_ert<false, false, true>(p, n_views, variant, skip, stream);
     } else {
-        if (tf) launch_variant<true, true, false>(p, n_views, variant, skip, stream);
-        else if (alpha_only) launch_variant<true, false, false>(p, n_views, variant, skip, stream);
-        else launch_variant<false, false, false>(p, n_views, variant, skip, stream);
+        if (tf) launch_ert<true, true, false>(p, n_views, variant, skip, stream);
+        else if (alpha_only) launch_ert<true, false, false>(p, n_views, variant, skip, stream);
+        else launch_ert<false, false, false>(p, n_views, variant, skip, stream);
     }
     return hipGetLastError();
 }
