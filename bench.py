@@ -434,7 +434,7 @@ def main():
     n_exec = vd.sum_over_ranks(dc["executed"], coll_dev)
     n_exec_zero = vd.sum_over_ranks(dc["executed_zero_alpha"], coll_dev)
     chunk_stats = {k: int(vd.sum_over_ranks(dc[k], coll_dev)) for k in ("chunks", "chunks_staged", "chunks_empty", "probes_failed",
-                                                                         "chunks_gathered")}
+                                                                         "chunks_gathered", "box_retries")}
 
     views_per_s = n_views * a.steps / elapsed
     gsamples = n_ref * a.steps / elapsed / 1e9

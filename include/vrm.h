@@ -290,7 +290,8 @@ VRM_API int vrm_image_read_ray_diagnostics(vrm_image *image, float *geom8);
 /* Same switch: counters summed over every diagnostics draw since the last reset -- [0] samples filtered and blended (N_exec),
  * [1] of those, samples whose filtered alpha was exactly 0 (they changed nothing; what finer skipping could still save),
  * [2] chunk prologues, [3] chunks staged into LDS and sampled, [4] chunks passed over as empty, [5] deep empty-space probes
- * that found something and were redone as plain chunks, [6] chunks marched with global gathers, [7] 0. */
+ * that found something and were redone as plain chunks, [6] chunks marched with global gathers, [7] box computations repeated
+ * with fewer steps because the first box did not fit the LDS tile. */
 VRM_API int vrm_diag_read_counters(vrm_ctx *ctx, uint64_t out[8], int reset);
 
 /* Reference-equivalent sample count (the unit of the Gsamples/s metric): the number of

@@ -327,7 +327,8 @@ class RayMarcher:
         """Counters of the diagnostics draws since the last reset (vrm_diag_read_counters) as a dict."""
         out = (ctypes.c_uint64 * 8)()
         _ffi.check(_ffi.lib().vrm_diag_read_counters(self._h, out, 1 if reset else 0))
-        names = ["executed", "executed_zero_alpha", "chunks", "chunks_staged", "chunks_empty", "probes_failed", "chunks_gathered"]
+        names = ["executed", "executed_zero_alpha", "chunks", "chunks_staged", "chunks_empty", "probes_failed", "chunks_gathered",
+                 "box_retries"]
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def synchronize(self):

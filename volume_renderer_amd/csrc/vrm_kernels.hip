@@ -372,40 +372,37 @@ __device__ __forceinline__ void wave_minmax(float &lo, float &hi)
     lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lo), 63));
     hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi), 63));
 }
-// the same on signed integers; the results come back wave-uniform (SGPRs)
-__device__ __forceinline__ void wave_minmax(int &lo, int &hi)
-{
-    asm volatile(VRM_DPP_MINMAX("i32") : "+v"(lo), "+v"(hi));
-    lo = __builtin_amdgcn_readlane(lo, 63);
-    hi = __builtin_amdgcn_readlane(hi, 63);
-}
 // three (min, max) pairs at once: six independent chains, so every stage's dependent instruction is five others away
-// and no wait states need padding (a chunk prologue reduces the box bounds of all three axes)
-#define VRM_DPP_STAGE6(CTRL)                                         \
-    "v_min_i32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"            \
-    "v_max_i32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"            \
-    "v_min_i32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"            \
-    "v_max_i32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"            \
-    "v_min_i32_dpp %4, %4, %4 " CTRL " bank_mask:0xf\n\t"            \
-    "v_max_i32_dpp %5, %5, %5 " CTRL " bank_mask:0xf\n\t"
-__device__ __forceinline__ void wave_minmax3(int lo[3], int hi[3])
+// and no wait states need padding (a chunk prologue reduces the box bounds of all three axes).  The results are left
+// in lane 63 of the six registers (the caller goes on computing there and reads the integers it needs with readlane):
+// the box bounds are reduced as floats and floored once, not per lane.
+#define VRM_DPP_STAGE6F(CTRL)                                        \
+    "v_min_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"            \
+    "v_min_f32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_f32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"            \
+    "v_min_f32_dpp %4, %4, %4 " CTRL " bank_mask:0xf\n\t"            \
+    "v_max_f32_dpp %5, %5, %5 " CTRL " bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_minmax3f_lane63(float lo[3], float hi[3])
 {
     asm volatile("s_nop 1\n\t"
-                 VRM_DPP_STAGE6("quad_perm:[1,0,3,2] row_mask:0xf")
-                 VRM_DPP_STAGE6("quad_perm:[2,3,0,1] row_mask:0xf")
-                 VRM_DPP_STAGE6("row_half_mirror row_mask:0xf")
-                 VRM_DPP_STAGE6("row_mirror row_mask:0xf")
-                 VRM_DPP_STAGE6("row_bcast:15 row_mask:0xa")
-                 VRM_DPP_STAGE6("row_bcast:31 row_mask:0xc")
+                 VRM_DPP_STAGE6F("quad_perm:[1,0,3,2] row_mask:0xf")
+                 VRM_DPP_STAGE6F("quad_perm:[2,3,0,1] row_mask:0xf")
+                 VRM_DPP_STAGE6F("row_half_mirror row_mask:0xf")
+                 VRM_DPP_STAGE6F("row_mirror row_mask:0xf")
+                 VRM_DPP_STAGE6F("row_bcast:15 row_mask:0xa")
+                 VRM_DPP_STAGE6F("row_bcast:31 row_mask:0xc")
                  "s_nop 1"
                  : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = __builtin_amdgcn_readlane(lo[a], 63);
-        hi[a] = __builtin_amdgcn_readlane(hi[a], 63);
-    }
 }
-#undef VRM_DPP_STAGE6
+#undef VRM_DPP_STAGE6F
+// (int)floor(x) in one instruction
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 #undef VRM_DPP_MINMAX
 #undef VRM_DPP_STAGE2
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -501,7 +498,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
     Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t iters = 0, n_inside = 0, n_exec = 0;
     // diagnostics build: per-lane count of filtered samples whose alpha came out exactly 0, and per-wave chunk statistics
-    uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0;
+    uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0, st_retry = 0;
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22; // per 2^-22 texel level
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
@@ -525,9 +522,15 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
     // the tile's cross-section times the chunk depth whatever the entry geometry.  Which lane takes which step in
     // which chunk does not change any lane's own dt sequence: the image is bit-identical.
     // margin of the "interior chunk" test below: rounding of the one-FMA texel coordinate against the exact in-box test
-    float eps_in[3];
+    // (as integer bounds on the chunk's box: the margin of the wave's worst lane, rounded outwards to whole texels)
+    int in_lo[3], in_hi[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) eps_in[a] = 0.02f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
+    for (int a = 0; a < 3; ++a) {
+        float e0 = 0.0f, eps = 0.021f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
+        wave_minmax(e0, eps);
+        in_lo[a] = uni((int)ceilf(g.u_lo[a] + eps));
+        in_hi[a] = uni((int)floorf(g.u_hi[a] - eps));
+    }
     int m_axis = 0;
     float sgn = 1.0f, smax = 0.0f;
     bool aligned;
@@ -559,6 +562,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
     // empty costs one prologue and drops back to lvl 0, where chunks are staged and sampled.  How the march is cut into
     // chunks does not change what a sample contributes (see the steps below), so this is as exact as plain skipping.
     int lvl = 0, lvl_run = 0;
+    const uint32_t lane_c0 = lane & 3u, lane_c1 = (lane >> 2) & 3u, lane_c2 = lane >> 4; // this lane's cell in an emptiness test
 #ifdef VRM_AB_ADAPT_KK
     int kk_start = (int)P.chunk_steps;    // first chunk length tried: what fitted last time, grown again while the tile has room
 #endif
@@ -606,28 +610,32 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
         // texel-space bounding box [lo, hi] of everything `nl` steps of every lane can touch; returns this lane's
         // "every step stays inside the volume (slab) with margin"
         auto chunk_box = [&](int nl, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
-            bool margin_ok = true;
+            // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test.  Per lane only
+            // the float extent of its steps; the wave's extent is reduced as floats and floored once, in lane 63, so the
+            // bounds land in SGPRs as integers.  (z of a slab-partitioned volume: samples outside the slab's own range fail
+            // the test too, so a chunk that lies in another rank's slab degenerates to `none` and only advances dt.)
+            const bool has = nl > 0;
+            const float nlf = (float)nl;
+            float mn[3], mx[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test.
-                // The bounds are floored per lane and reduced as integers: the results land in SGPRs as they are.
-                // (z of a slab-partitioned volume: samples outside the slab's own range fail the test too, so a chunk
-                // that lies in another rank's slab degenerates to `none` and only advances dt)
-                const float ue = __builtin_fmaf((float)nl, du[a], ua[a]);
-                const float fl = fminf(ua[a], ue) - 0.01f, fh = fmaxf(ua[a], ue) + 0.01f;
-                int li = (int)floorf(fmaxf(fl, g.u_lo[a] - 0.5f)), hh = (int)floorf(fminf(fh, g.u_hi[a])) + 1;
-                if (nl <= 0) { li = 1 << 28; hh = -(1 << 28); }
-                else margin_ok = margin_ok && (fl - eps_in[a] >= g.u_lo[a]) && (fh + eps_in[a] <= g.u_hi[a]);
-#ifdef VRM_AB_SPLIT_REDUCE
-                wave_minmax(li, hh);
-#endif
+                const float ue = __builtin_fmaf(nlf, du[a], ua[a]);
+                mn[a] = has ? fminf(ua[a], ue) : __builtin_inff();
+                mx[a] = has ? fmaxf(ua[a], ue) : -__builtin_inff();
+            }
+            wave_minmax3f_lane63(mn, mx);
+            bool inter = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // (a wave without steps: +-inf clamp to +-2^28, an empty box)
+                const int li = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mn[a] - 0.01f, g.u_lo[a] - 0.5f, 0x1p28f)), 63);
+                const int hh = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mx[a] + 0.01f, -0x1p28f, g.u_hi[a])), 63) + 1;
+                // interior: min - 0.01 >= li >= in_lo >= u_lo + eps and max + 0.01 < hh <= in_hi <= u_hi - eps
+                inter = inter && li >= in_lo[a] && hh <= in_hi[a];
                 lo[a] = li;
                 hi[a] = hh;
             }
-#ifndef VRM_AB_SPLIT_REDUCE
-            wave_minmax3(lo, hi);
-#endif
-            return margin_ok;
+            return inter;
         };
         // ---- exact empty-space skipping: if every texel the chunk can touch has alpha == 0, every sample has
         // a == 0, alpha_src = 1 - exp(0) = 0 exactly and neither colour nor alpha changes (wgsl:150-159); only
@@ -639,11 +647,19 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
             const int c0x = max(ilo[0], 0) >> sh, c0y = max(ilo[1], 0) >> sh, c0z = max(ilo[2], 0) >> sh;
             const int ncx = (min(ihi[0], mxx) >> sh) - c0x + 1, ncy = (min(ihi[1], mxy) >> sh) - c0y + 1,
                       ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
+            const uint32_t rnd = (1u << lvl) - 1u;
+            const uint32_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
+            const uint8_t *occl = g.occ + g.occ_off[lvl];
+            if (ncx <= 4 && ncy <= 4 && ncz <= 4) {
+                // the usual case: the cells are a corner of the 4x4x4 block the lanes stand for (lane = x + 4*y + 16*z), one
+                // byte per lane at a lane-constant offset from the block's first cell (a level fits 32-bit offsets)
+                const uint32_t first = ((uint32_t)c0z * od1 + (uint32_t)c0y) * od0 + (uint32_t)c0x;
+                const uint32_t off = first + (lane_c2 * od1 + lane_c1) * od0 + lane_c0;
+                const bool mine = (int)lane_c0 < ncx && (int)lane_c1 < ncy && (int)lane_c2 < ncz;
+                return __builtin_amdgcn_ballot_w64(mine && occl[off] != 0) == 0ull;
+            }
             const int ncxy = ncx * ncy, nc = ncxy * ncz;
             if (nc > 128) return false;
-            const uint32_t rnd = (1u << lvl) - 1u;
-            const size_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
-            const uint8_t *occl = g.occ + g.occ_off[lvl];
             const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
             bool occ = false;
 #pragma unroll
@@ -652,7 +668,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
                 if (c < nc) {
                     const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
                     const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
-                    occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * od0 + (size_t)(c0x + cx)] != 0;
+                    occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * (size_t)od0 + (size_t)(c0x + cx)] != 0;
                 }
             }
             return __builtin_amdgcn_ballot_w64(occ) == 0ull;
@@ -662,8 +678,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
             // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
             const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
             n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
-            const bool margin_ok = chunk_box(n_lane, ilo, ihi); // per lane: every step of this chunk stays inside with margin
-            interior = __builtin_amdgcn_ballot_w64(!margin_ok) == 0ull;
+            interior = chunk_box(n_lane, ilo, ihi); // every step of every lane stays inside the volume (slab) with margin
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-unit boundary: the staging loads are whole 16-byte quads of the bricked volume
             x0u = PACKED ? ilo[0] >> 2 : ilo[0];
@@ -677,6 +692,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
             fits = !none && pitch <= PX_MAX && (long long)nz * slice + (PACKED ? 1 : 0) <= (long long)CAP;
             if (fits || none || kk == 1 || lvl > 0) break; // (a deep empty-space probe is never staged: it need not fit)
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
+            if (DIAG) ++st_retry;
         }
 #ifdef VRM_AB_ADAPT_KK
         if (fits && !empty) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
@@ -930,6 +946,7 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
             atomicAdd(&P.diag_counters[4], (unsigned long long)st_empty);
             atomicAdd(&P.diag_counters[5], (unsigned long long)st_probe_fail);
             atomicAdd(&P.diag_counters[6], (unsigned long long)st_fallback);
+            atomicAdd(&P.diag_counters[7], (unsigned long long)st_retry);
         }
     }
 }
