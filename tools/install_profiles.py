@@ -14,7 +14,7 @@ N_SIMD, N_CU = 1024, 256   # MI355X: 256 CUs x 4 SIMDs
 O, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
 for f in ["bench_final_c3.json", "bench_final_c3_under_rocprofv3.json", "bench_final_c3_kernel_stats.csv", "bench_final_c2.json",
-          "bench_final_c4.json", "bench_final_c3_tf.json", "bench_final_c1.json"]:
+          "bench_final_c4.json", "bench_final_c3_tf.json", "bench_final_c1.json", "c5_slab_rank.json", "c5_slab_rank.log"]:
     if os.path.exists(os.path.join(O, f)):
         shutil.copy(os.path.join(O, f), os.path.join(P, f))
 passes = {"final_c3_skip1": ("pmc_final_skip1.txt", 32, "C3:kernel1:skip1"), "final_c3_skip0": ("pmc_final_skip0.txt", 32, "C3:kernel1:skip0"),
@@ -62,6 +62,9 @@ for tag, (name, views, key) in passes.items():
         sec["executed_zero_alpha_frac"] = round(int(m.group(4)) / n_exec, 4)
         sec["chunk_prologues_per_view"] = int(m.group(5)) // int(m.group(1))
         sec["chunks_staged_per_view"] = int(m.group(6)) // int(m.group(1))
+        mr = re.search(r"box_retries=(\d+)", s)
+        if mr:
+            sec["box_retries_per_view"] = int(mr.group(1)) // int(m.group(1))
     t[key]["secondary"] = sec
     print("   secondary:", {k: v for k, v in sec.items() if k != "mall_note"})
 json.dump(t, open(tj_path, "w"), indent=1)
