@@ -180,9 +180,10 @@ VRM_API int vrm_load_dat(vrm_ctx *ctx, const char *dat_path);
 
 /* loaders::netcdf::open_voxel_grid (loaders/netcdf.rs:34-69): read variable `color(c,z,y,x)` (f32, c = 4), make a
  * fresh x*y*z grid (attenuation and TF reset, netcdf.rs:47) and quantise `(v*255.0) as u8` per channel (netcdf.rs:54-57,
- * on the GPU).  Container: netCDF classic (CDF-1, CDF-2, CDF-5).  A NetCDF-4/HDF5 file -- what the reference's
- * netcdf crate and scripts/diffdvr.py:278 write -- is recognised and refused with VRM_ERR_IO and a message naming the
- * conversion (`nccopy -k cdf5`); the data model is the same. */
+ * on the GPU).  Containers: NetCDF-4 = HDF5 -- what the reference's netcdf crate (loaders/netcdf.rs:10,35) and
+ * scripts/diffdvr.py:278 write; the subset csrc/vrm_hdf5.cpp lists: contiguous, chunked and single-chunk f32 datasets,
+ * deflate / shuffle / fletcher32 -- and netCDF classic (CDF-1, CDF-2, CDF-5).  HDF5 features outside the subset (dense
+ * link storage, newer chunk indices) and sizes that do not fit the file are VRM_ERR_IO with a message. */
 VRM_API int vrm_load_netcdf(vrm_ctx *ctx, const char *path);
 /* loaders::netcdf::write_voxel_grid (loaders/netcdf.rs:8-31): dimensions c=4,z,y,x and `color` = voxel/255.0 as f32,
  * written as a classic file (CDF-1 below 2 GiB, CDF-2 below 4 GiB, CDF-5 beyond). */
