@@ -12,7 +12,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--o
                        "--save-temps", "-c", root + "/volume_renderer_amd/csrc/vrm_kernels.hip", "-o", "k.o"], cwd="/tmp/isa",
                       stderr=subprocess.DEVNULL)
 lines = open("/tmp/isa/vrm_kernels-hip-amdgcn-amd-amdhsa-gfx950.s").read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and "march_lds_kernel" + frag in l and l.rstrip().split(";")[0].rstrip().endswith(":"))
+name = frag if "kernel" in frag else "march_lds_kernel" + frag   # e.g. march_wg_kernelILb0ELb0ELb1ELi6144ELb0ELb0E
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and name in l and l.rstrip().split(";")[0].rstrip().endswith(":"))
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 open("/tmp/isa/sel.s", "w").write("\n".join(lines[start:end + 1]))
 blocks, cur = [], ["entry", 0, 0, 0, 0, []]
@@ -34,4 +35,6 @@ for ln in lines[start:end + 1]:
 blocks.append(cur)
 for b in blocks:
     print(f"{b[0]:12s} V {b[1]:4d} S {b[2]:4d} DS {b[3]:2d} G {b[4]:2d} -> {','.join(b[5])}")
+meta = [l.strip() for l in lines[end:end + 80] if re.search(r"NumVgprs|NumSgprs|ScratchSize|Occupancy|LDSByteSize", l)]
+print("; ".join(meta))
 print("total V", sum(b[1] for b in blocks), "S", sum(b[2] for b in blocks), "; listing in /tmp/isa/sel.s")
