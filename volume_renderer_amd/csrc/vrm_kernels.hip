@@ -961,374 +961,6 @@ __global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 3: ONE staged box per 16x16-pixel tile, shared by the four waves of a 256-thread workgroup.
-//
-// The same march as variant 1 -- plane-front chunks, box from the lanes' extents, occupancy test with long strides, LDS-DMA
-// staging, the same step loop, hence (the sample arithmetic does not depend on the chunking) bit-identical accumulators --
-// but the four 8x8-pixel wave tiles of a 16x16-pixel block advance a common plane and share the chunk's box: its
-// cross-section grows by (16+h)^2 / (4 (8+h)^2) per wave (h = the halo and alignment texels), so a wave needs about half the
-// LDS and twice as many waves are resident.  Per chunk the waves meet three times: rear-most lane / anybody active,
-// box extents (once more per repeated box), staging complete.  Exchanges go through two alternating 128-byte records in LDS,
-// one barrier each.  Production path only: the diagnostics build and slab-partitioned volumes run variant 1.
-// ---------------------------------------------------------------------------------------------
-template <bool ALPHA_ONLY, bool USE_TF, bool SKIP, int CAP, bool PACKED, bool ERT>
-__global__ void __launch_bounds__(256, (CAP <= 5056 ? 8 : CAP <= 6784 ? 6 : CAP <= 8128 ? 5 : 4)) march_wg_kernel(const VrmMarchParams P)
-{
-    static_assert(!PACKED || ALPHA_ONLY, "the packed source holds the alpha channel only");
-    constexpr int PX_MAX = 64; // one staging instruction holds at least one whole row
-    __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
-    __shared__ __attribute__((aligned(16))) float xch[2][4][8];
-    const VrmGridDev &g = P.grid;
-    const uint32_t view = blockIdx.y;
-    // tile order: as variant 1, with 4x4 workgroup tiles per 64x64-pixel super-block
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t j = slot >> 4, within = slot & 15u;
-    const uint32_t per_row = P.sblocks_x >> 3;
-    const uint32_t sby = j / per_row, m = j - sby * per_row;
-    const uint32_t sbx = ((xcd - sby) & 7u) + 8u * m;
-    const uint32_t tx = sbx * 4u + (within & 3u), ty = sby * 4u + (within >> 2);
-    if (tx * 16u >= P.width || ty * 16u >= P.height) return; // workgroup-uniform, before any barrier
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = (uint32_t)uni((int)(threadIdx.x >> 6));
-    const uint32_t px = tx * 16u + (wv & 1u) * 8u + (lane & 7u), py = ty * 16u + (wv >> 1) * 8u + (lane >> 3);
-    const bool in_image = px < P.width && py < P.height;
-    const VrmViewDesc &v = P.views[view];
-    const Ray ray = setup_ray(v, g, in_image ? px : 0u, in_image ? py : 0u, P.width, P.height);
-
-    Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22;
-    bool active = in_image && ray.hit;
-    float dt = ray.t_min;
-
-    // Workgroup-wide (min, max) of three pairs.  Lane `src` of every wave holds the wave's values; each wave posts them, the
-    // waves meet, everybody reads the four records.  The two records alternate: a record is rewritten two exchanges later,
-    // i.e. after the barrier that every wave reaches only when it has finished reading it.
-    int xb = 0;
-    auto wg_minmax3 = [&](float lo[3], float hi[3], uint32_t src) __attribute__((always_inline)) {
-        float *rec = xch[xb][wv];
-        if (lane == src) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                rec[2 * a] = lo[a];
-                rec[2 * a + 1] = hi[a];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = fminf(fminf(xch[xb][0][2 * a], xch[xb][1][2 * a]), fminf(xch[xb][2][2 * a], xch[xb][3][2 * a]));
-            hi[a] = fmaxf(fmaxf(xch[xb][0][2 * a + 1], xch[xb][1][2 * a + 1]), fmaxf(xch[xb][2][2 * a + 1], xch[xb][3][2 * a + 1]));
-        }
-        xb ^= 1;
-    };
-    auto unif = [&](float x) __attribute__((always_inline)) -> float {
-        return __builtin_bit_cast(float, uni(__builtin_bit_cast(int, x)));
-    };
-
-    float rs[3], du[3], bla[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        rs[a] = ray.rd[a] * g.tex_scale[a];
-        du[a] = rs[a] * (VRM_STEP_SIZE * 1.01f);
-        bla[a] = __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]);
-    }
-    // per-wave margins of the interior test (which step loop a wave runs is its own business)
-    int in_lo[3], in_hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float e0 = 0.0f, eps = 0.021f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-        wave_minmax(e0, eps);
-        in_lo[a] = uni((int)ceilf(g.u_lo[a] + eps));
-        in_hi[a] = uni((int)floorf(g.u_hi[a] - eps));
-    }
-    // the plane's axis: over all four waves
-    int m_axis = 0;
-    float sgn = 1.0f, smax = 0.0f;
-    bool aligned;
-    {
-        float amax[3], amin[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            amin[a] = active ? du[a] : __builtin_inff();
-            amax[a] = active ? du[a] : -__builtin_inff();
-            wave_minmax(amin[a], amax[a]);
-        }
-        wg_minmax3(amin, amax, 0);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            amin[a] = unif(amin[a]);
-            amax[a] = unif(amax[a]);
-        }
-        float best = -1.0f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float mag = fmaxf(amax[a], -amin[a]);
-            if (mag > best) { best = mag; m_axis = a; sgn = amax[a] >= -amin[a] ? 1.0f : -1.0f; smax = mag; }
-        }
-        const float slowest = sgn > 0.0f ? (m_axis == 0 ? amin[0] : m_axis == 1 ? amin[1] : amin[2])
-                                         : -(m_axis == 0 ? amax[0] : m_axis == 1 ? amax[1] : amax[2]);
-        aligned = slowest > 0.25f * smax;
-    }
-    const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]);
-    const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
-    int steps_left = VRM_MAX_STEP_AMOUNT;
-    int lvl = 0, lvl_run = 0;
-    const uint32_t lane_c0 = lane & 3u, lane_c1 = (lane >> 2) & 3u, lane_c2 = lane >> 4;
-
-    for (;;) {
-        float ua[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(dt, rs[a], bla[a]);
-        const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
-        // ---- meeting 1: is anybody still marching, and where is the rear-most lane of the workgroup ----
-        float rear;
-        {
-            float e_lo[3] = {aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f, 0.0f, 0.0f};
-            float e_hi[3] = {__builtin_amdgcn_ballot_w64(active) != 0ull ? 1.0f : 0.0f, 0.0f, 0.0f};
-            wg_minmax3(e_lo, e_hi, 0);
-            if (unif(e_hi[0]) == 0.0f) break;
-            rear = unif(e_lo[0]);
-        }
-        int kk = (int)P.chunk_steps << lvl;
-        int n_lane;
-        int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
-        int x0u;
-        bool none, fits, interior;
-        // ---- meeting 2: the box of everything `nl` steps of every lane of the workgroup can touch ----
-        auto chunk_box = [&](int nl, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
-            const bool has = nl > 0;
-            const float nlf = (float)nl;
-            float mn[3], mx[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float ue = __builtin_fmaf(nlf, du[a], ua[a]);
-                mn[a] = has ? fminf(ua[a], ue) : __builtin_inff();
-                mx[a] = has ? fmaxf(ua[a], ue) : -__builtin_inff();
-            }
-            wave_minmax3f_lane63(mn, mx);
-            wg_minmax3(mn, mx, 63);
-            bool inter = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int li = uni(floor_to_int(__builtin_amdgcn_fmed3f(mn[a] - 0.01f, g.u_lo[a] - 0.5f, 0x1p28f)));
-                const int hh = uni(floor_to_int(__builtin_amdgcn_fmed3f(mx[a] + 0.01f, -0x1p28f, g.u_hi[a]))) + 1;
-                inter = inter && li >= in_lo[a] && hh <= in_hi[a];
-                lo[a] = li;
-                hi[a] = hh;
-            }
-            return inter;
-        };
-        auto box_is_empty = [&]() __attribute__((always_inline)) -> bool {
-            const int sh = 2 + lvl;
-            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const int c0x = max(ilo[0], 0) >> sh, c0y = max(ilo[1], 0) >> sh, c0z = max(ilo[2], 0) >> sh;
-            const int ncx = (min(ihi[0], mxx) >> sh) - c0x + 1, ncy = (min(ihi[1], mxy) >> sh) - c0y + 1,
-                      ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
-            const uint32_t rnd = (1u << lvl) - 1u;
-            const uint32_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
-            const uint8_t *occl = g.occ + g.occ_off[lvl];
-            if (ncx <= 4 && ncy <= 4 && ncz <= 4) {
-                const uint32_t first = ((uint32_t)c0z * od1 + (uint32_t)c0y) * od0 + (uint32_t)c0x;
-                const uint32_t off = first + (lane_c2 * od1 + lane_c1) * od0 + lane_c0;
-                const bool mine = (int)lane_c0 < ncx && (int)lane_c1 < ncy && (int)lane_c2 < ncz;
-                return __builtin_amdgcn_ballot_w64(mine && occl[off] != 0) == 0ull;
-            }
-            const int ncxy = ncx * ncy, nc = ncxy * ncz;
-            if (nc > 128) return false;
-            const float inv_xy = __builtin_amdgcn_rcpf((float)ncxy), inv_x = __builtin_amdgcn_rcpf((float)ncx);
-            bool occ = false;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int c = (int)lane + 64 * r;
-                if (c < nc) {
-                    const int cz = (int)(((float)c + 0.5f) * inv_xy), rem = c - cz * ncxy;
-                    const int cy = (int)(((float)rem + 0.5f) * inv_x), cx = rem - cy * ncx;
-                    occ |= occl[((size_t)(c0z + cz) * od1 + (size_t)(c0y + cy)) * (size_t)od0 + (size_t)(c0x + cx)] != 0;
-                }
-            }
-            return __builtin_amdgcn_ballot_w64(occ) == 0ull;
-        };
-        bool empty = false;
-        for (;;) {
-            const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
-            n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
-            interior = chunk_box(n_lane, ilo, ihi);
-            none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1;
-            x0u = PACKED ? ilo[0] >> 2 : ilo[0];
-            if (x0u >= 0) x0u &= ~3;
-            if (!PACKED) ilo[0] = x0u;
-            nx = (PACKED ? ihi[0] >> 2 : ihi[0]) - x0u + 1; ny = ihi[1] - ilo[1] + 1; nz = ihi[2] - ilo[2] + 1;
-            pitch = (nx + 3) & ~3;
-            slice = ny * pitch;
-            slice += (slice & 4) ? 0 : 4;
-            fits = !none && pitch <= PX_MAX && (long long)nz * slice + (PACKED ? 1 : 0) <= (long long)CAP;
-            if (fits || none || kk == 1 || lvl > 0) break;
-            kk = (3 * kk) >> 2;
-        }
-        if (none) empty = true;
-        else {
-            if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps; the box must cover all of them
-                kk = 8;
-                n_lane = active ? min(8, steps_left) : 0;
-                (void)chunk_box(n_lane, ilo, ihi);
-            }
-            if (SKIP) empty = box_is_empty();
-        }
-        if (SKIP && lvl > 0 && !empty) { // the deep probe found something: back to plain chunks, nothing was advanced
-            lvl = 0;
-            lvl_run = 0;
-            continue;
-        }
-        if (fits && !empty) {
-            // ---- stage the box; the waves share the slices (meeting 1 and 2 lie between the previous chunk's gathers and
-            // these writes) ----
-            const int rows = ny * nz;
-            const float inv_ny = __builtin_amdgcn_rcpf((float)ny);
-            const int mxx = (int)g.dim[0] - 1, mxy = (int)g.dim[1] - 1, mxz = (int)g.dim[2] - 1;
-            const uint32_t *src = PACKED ? g.abricks : g.bricks;
-            const uint32_t src_nbx = PACKED ? g.nbxa : g.nbx;
-            if (x0u >= 0 && x0u + pitch <= (PACKED ? (int)(g.nbxa * 4u) : (int)g.dim[0])) {
-                const int qpr = pitch >> 2;
-                const int rpw = (int)(64.5f * __builtin_amdgcn_rcpf((float)qpr));
-                const int eyl = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)qpr)), q = (int)lane - eyl * qpr;
-                const uint32_t bx = ((uint32_t)x0u >> 2) + (uint32_t)q;
-                const size_t zslab = (size_t)src_nbx * g.nby * 128u;
-                for (int eb = 0; eb * rpw < ny; ++eb) {
-                    const int ey = eb * rpw + eyl;
-                    const bool lane_on = eyl < rpw && ey < ny;
-                    const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                    const uint32_t voff = (((gy >> 2) * src_nbx + bx) * 8u + (gy & 3u)) * 16u;
-                    uint32_t *drow = &tile[eb * rpw * pitch];
-                    for (int ez = (int)wv; ez < nz; ez += 4) {
-                        const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
-                        const char *zbase = reinterpret_cast<const char *>(src) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
-                        if (lane_on)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(zbase + voff),
-                                                             (__attribute__((address_space(3))) void *)(drow + ez * slice), 16, 0, 0);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                // the box sticks out of the volume in x: one texel per lane, clamp-to-edge per texel
-                const int rpi = (int)(64.5f * __builtin_amdgcn_rcpf((float)pitch));
-                const int er = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)pitch)), ex = (int)lane - er * pitch;
-                const int tx0 = PACKED ? 4 * (x0u + ex) : x0u + ex;
-                const uint32_t gx = (uint32_t)min(max(tx0, 0), mxx);
-                const bool lane_on = er < rpi && ex < nx;
-                for (int row = er + (int)wv * rpi; row < rows; row += 4 * rpi) {
-                    const int ez = (int)(((float)row + 0.5f) * inv_ny);
-                    const int ey = row - ez * ny;
-                    const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
-                    const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
-                    if (lane_on) {
-                        const uint32_t *vrow = g.vox + ((size_t)gz * g.dim[1] + gy) * g.dim[0];
-                        uint32_t w = vrow[gx];
-                        if (PACKED) {
-                            w >>= 24;
-#pragma unroll
-                            for (int k = 1; k < 4; ++k) w |= (vrow[min(max(tx0 + k, 0), mxx)] >> 24) << (8 * k);
-                        }
-                        tile[ez * slice + ey * pitch + ex] = w;
-                    }
-                }
-            }
-            __syncthreads(); // meeting 3: every wave's share of the box is in the tile
-        }
-        if (empty) {
-            advance_exact(dt, active, ray.t_max, n_lane);
-            steps_left -= n_lane;
-            active = active && steps_left > 0;
-            if (SKIP && VRM_SKIP_MAX_LEVEL > 0) {
-                if (++lvl_run >= VRM_SKIP_ESCALATE && lvl < VRM_SKIP_MAX_LEVEL && g.occ_off[lvl + 1] != 0u) { ++lvl; lvl_run = 0; }
-            }
-            continue;
-        }
-        lvl_run = 0;
-        if (fits) {
-            const float o1 = (float)ilo[1], o2 = (float)ilo[2];
-            const float fpx4 = (float)(4 * pitch), fsl4 = (float)(4 * slice);
-            const float x04 = -4.0f * (float)x0u;
-            const int pitch4 = 4 * pitch, slice4 = 4 * slice;
-            const float amax4 = (float)(4 * ((nz - 2) * slice + (ny - 2) * pitch + (nx - (PACKED ? 1 : 2))));
-            const char *tile_b = reinterpret_cast<const char *>(tile);
-            auto ld = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(tile_b + byte_off); };
-            auto steps = [&](auto interior_c) {
-                constexpr bool INTERIOR = decltype(interior_c)::value;
-                for (int jj = 0; jj < kk; ++jj) {
-                    if (jj < n_lane && active) {
-                        bool inside = true;
-                        if constexpr (!INTERIOR) {
-                            const float p0 = ray.ro[0] + ray.rd[0] * dt;
-                            const float p1 = ray.ro[1] + ray.rd[1] * dt;
-                            const float p2 = ray.ro[2] + ray.rd[2] * dt;
-                            inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
-                                     (p1 < g.box_max[1]) & (p2 < g.in_max_z);
-                        }
-                        bool done = false;
-                        if (inside) {
-                            const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
-                            const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
-                            const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
-                            const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
-                            const float fc = PACKED ? floorf(f0 * 0.25f) : f0;
-                            const float af = __builtin_fmaf(f2 - o2, fsl4, __builtin_fmaf(f1 - o1, fpx4, __builtin_fmaf(fc, 4.0f, x04)));
-                            const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax4);
-                            const int a1 = a0 + pitch4, a2 = a0 + slice4, a3 = a2 + pitch4;
-                            if constexpr (PACKED) {
-                                const uint32_t sh = (uint32_t)(int)f0 & 3u;
-                                uint32_t w[4];
-                                w[0] = __builtin_amdgcn_alignbyte(ld(a0 + 4), ld(a0), sh);
-                                w[1] = __builtin_amdgcn_alignbyte(ld(a1 + 4), ld(a1), sh);
-                                w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
-                                w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
-                                done = shade_packed<USE_TF, ERT>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, nullptr);
-                            } else {
-                                uint32_t c[8];
-                                c[0] = ld(a0); c[1] = ld(a0 + 4);
-                                c[2] = ld(a1); c[3] = ld(a1 + 4);
-                                c[4] = ld(a2); c[5] = ld(a2 + 4);
-                                c[6] = ld(a3); c[7] = ld(a3 + 4);
-                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, nullptr);
-                            }
-                        }
-                        dt += VRM_STEP_SIZE;
-                        active = !(done || dt >= ray.t_max);
-                    }
-                }
-            };
-            if (interior) steps(std::true_type{});
-            else steps(std::false_type{});
-        } else {
-            for (int jj = 0; jj < kk; ++jj) {
-                if (jj < n_lane && active) {
-                    const float p0 = ray.ro[0] + ray.rd[0] * dt;
-                    const float p1 = ray.ro[1] + ray.rd[1] * dt;
-                    const float p2 = ray.ro[2] + ray.rd[2] * dt;
-                    const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
-                                        (p1 < g.box_max[1]) & (p2 < g.in_max_z);
-                    bool done = false;
-                    if (inside) {
-                        const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
-                        const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
-                        const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
-                        const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
-                        uint32_t c[8];
-                        fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
-                    }
-                    dt += VRM_STEP_SIZE;
-                    active = !(done || dt >= ray.t_max);
-                }
-            }
-        }
-        steps_left -= n_lane;
-        active = active && steps_left > 0;
-    }
-    finish_colour<ALPHA_ONLY, USE_TF>(acc);
-    if (in_image) store_pixel<false>(v, P, px, py, acc, ray, 0u, 0u, 0u);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Reference-equivalent sample count: the number of loop iterations raymarch() (wgsl:139-187) executes
 // for every ray of a view when the early exit `alpha >= 1.0` does not fire (it cannot for
 // a*attenuation*0.001 < ln 2).  Pure geometry: the same dt lattice, no sampling.
@@ -1683,36 +1315,6 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
     if (variant == 0) {
         const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
-    } else if (variant >= 3 && !D && p.grid.slab == 0) {
-        // one box per 16x16-pixel tile, shared by the four waves of a workgroup (production path only)
-        if constexpr (!D) {
-            const dim3 grid(p.sblocks_x * p.sblocks_y * 16u, n_views, 1), block(256, 1, 1);
-            float tps = 0.0f;
-            for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
-#define VRM_WG(CAPV, DEPTH, PK)                                                                                   \
-    do {                                                                                                          \
-        if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_wg_kernel<A, T, true, CAPV, PK, E>), grid, block, 0, stream, p);       \
-        else hipLaunchKernelGGL((march_wg_kernel<A, T, false, CAPV, PK, E>), grid, block, 0, stream, p);           \
-    } while (0)
-#define VRM_WG_SRC(CAPV)                                                                                          \
-    do {                                                                                                          \
-        bool done = false;                                                                                        \
-        if constexpr (A) {                                                                                        \
-            if (p.grid.abricks != nullptr && p.packed_alpha != 0) {                                               \
-                VRM_WG(CAPV, 15.0f, true);                                                                        \
-                done = true;                                                                                      \
-            }                                                                                                     \
-        }                                                                                                         \
-        if (!done) VRM_WG(CAPV, 8.0f, false);                                                                     \
-    } while (0)
-            // LDS words per workgroup: 24 KB -> 6 workgroups = 24 waves per CU; 19.75 KB -> 8 = 32 waves; 31.75 KB -> 5 = 20 waves
-            if (variant == 4) VRM_WG_SRC(5056);
-            else if (variant == 5) VRM_WG_SRC(8128);
-            else VRM_WG_SRC(6144);
-#undef VRM_WG_SRC
-#undef VRM_WG
-        }
     } else {
         const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
         // texels a ray advances per step (the step is 0.001 world units whatever the resolution, wgsl:126)
