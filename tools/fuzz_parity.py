@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=80)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="evaluate this case only (the random stream still runs through all of them)")
     ap.add_argument("--max-dim", type=int, default=70)
     ap.add_argument("--max-res", type=int, default=140)
     ap.add_argument("--slab-cases", type=int, default=30, help="sort-last cases: production slab partials vs the oracle's")
@@ -76,11 +77,17 @@ def main():
         for k, v in opts.items():
             rm.set_option(k, v)
         desc = f"case {case}: dims {dims} {kind} image {W}x{H} att {att} tf {tf} cam {mode} {np.round(pos, 3).tolist()} opts {list(opts.values())}"
+        if a.only >= 0 and case != a.only:
+            continue
         try:
             configure(rm, vox, att, tf)
             got = draw(rm, vr, cam, W, H)
             if att < 600.0:
-                check(orc, got, vox, cam, W, H, att, tf)
+                # far cameras: the oracle's own sample position ro + rd*dt is rounded at the magnitude of ro (an ulp of 400 is
+                # 0.004 texel of a 130-texel volume) and the kernel's one-FMA texel coordinate carries a different error of
+                # the same size; the f32 gate widens in proportion, the 8-bit gates (<= 1 LSB, RMSE) stay as they are
+                far = float(np.linalg.norm(pos)) * max(dims) / 2.0e4
+                check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=max(1.0, far))
             else:
                 # the exact `alpha >= 1.0` exit can fire (attenuation >= 693): WHEN it fires depends on the last ulp of a
                 # continuous quantity, so iteration counts may differ by a step; image and accumulators must still agree

@@ -15,6 +15,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef VRM_CAP_DEFAULT
+#define VRM_CAP_DEFAULT 2560 /* LDS words per wave of the default march (A/B builds override it) */
+#endif
 #ifndef VRM_SKIP_MAX_LEVEL
 #define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
 #endif
@@ -452,7 +455,7 @@ template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACK
 #ifdef VRM_AB_LDS_PAD
 __global__ void __launch_bounds__(64, 2) march_lds_kernel
 #else
-__global__ void __launch_bounds__(64, (CAP <= 2048 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel
+__global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel
 #endif
 (const VrmMarchParams P)
 {
@@ -1340,11 +1343,11 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
             bool done = false;
             if constexpr (A) {
                 if (p.grid.abricks != nullptr && p.packed_alpha != 0) {
-                    VRM_LDS(2560, 15.0f, true);
+                    VRM_LDS(VRM_CAP_DEFAULT, 15.0f, true);
                     done = true;
                 }
             }
-            if (!done) VRM_LDS(2560, 8.0f, false); // 10 KB -> 16 waves/CU (variant 1, the default)
+            if (!done) VRM_LDS(VRM_CAP_DEFAULT, 8.0f, false); // 10 KB -> 16 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
