@@ -451,6 +451,12 @@ __device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_m
     }
 }
 
+// what the march kernel decides per chunk before it stages and samples (see `plan` in the kernel)
+struct ChunkPlan {
+    int n_lane, kk, ilo[3], ihi[3], nx, ny, nz, pitch, slice, x0u;
+    bool none, fits, interior, empty;
+};
+
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT>
 #ifdef VRM_AB_LDS_PAD
 __global__ void __launch_bounds__(64, 2) march_lds_kernel
@@ -575,50 +581,24 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     // chunks does not change what a sample contributes (see the steps below), so this is as exact as plain skipping.
     int lvl = 0, lvl_run = 0;
     const uint32_t lane_c0 = lane & 3u, lane_c1 = (lane >> 2) & 3u, lane_c2 = lane >> 4; // this lane's cell in an emptiness test
-#ifdef VRM_AB_ADAPT_KK
-    int kk_start = (int)P.chunk_steps;    // first chunk length tried: what fitted last time, grown again while the tile has room
-#endif
 
-    for (;;) {
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-
-        // ---- this chunk: steps per lane and the texel-space bounding box of everything they touch ----
+    // One chunk's plan: steps per lane, the box, how it lies in the tile, whether it is empty.  A function of the ray state
+    // (dt, active, steps left) and the stride level alone, so it can be made for the NEXT chunk while the current chunk's
+    // box is still in flight (look-ahead below).
+    auto plan = [&](const float dt, const bool active, const int steps_left, const int lvl, ChunkPlan &q) __attribute__((always_inline)) {
         float ua[3];
 #pragma unroll
         // (the formula the samples are filtered at: the box below then holds their texels whatever the camera distance --
         // the exact position ro + rd*dt, rounded at the magnitude of ro, differs from it by up to 0.06 texel at radius 1000)
         for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(dt, rs[a], bla[a]);
-        if (!DIAG && g.slab) {
-            // Slab-partitioned volume: this rank marches the whole volume's lattice but blends only its slab's samples.
-            // (The diagnostics build walks every step so that its per-ray counts stay those of the unpartitioned march.)
-            const float uz = ua[2], dz = du[2], lo1 = g.u_lo[2] - 1.0f, hi1 = g.u_hi[2] + 1.0f; // one texel of margin
-            // past the slab and moving away: nothing left to blend, the accumulators are final
-            if (dz > 0.0f ? uz >= hi1 : (dz < 0.0f && uz < lo1)) active = false;
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
-            // before the slab: advance the running dt sum up to the slab's entry plane without a chunk prologue per K
-            // steps (du carries 1 % slack, so the step count errs on the short side)
-            float ff = 0.0f;
-            if (dz > 0.0f && uz < lo1) ff = (lo1 - uz) / dz;
-            else if (dz < 0.0f && uz >= hi1) ff = (hi1 - uz) / dz;
-            const int nff = uni((int)fminf(wave_min(active ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
-            if (nff > 0) {
-                advance_exact(dt, active, ray.t_max, nff);
-                steps_left -= nff;
-                active = active && steps_left > 0;
-                continue;
-            }
-        }
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
-#ifdef VRM_AB_ADAPT_KK
-        int kk = lvl > 0 ? (int)P.chunk_steps << lvl : kk_start;
-#else
         int kk = (int)P.chunk_steps << lvl; // chunk length: the steps of the rear-most lane
-#endif
-        int n_lane;                  // steps of this lane in this chunk
-        int ilo[3], ihi[3], nx, ny, nz, pitch, slice;
-        int x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
-        bool none, fits, interior;
+        int &n_lane = q.n_lane;      // steps of this lane in this chunk
+        int *ilo = q.ilo, *ihi = q.ihi;
+        int &nx = q.nx, &ny = q.ny, &nz = q.nz, &pitch = q.pitch, &slice = q.slice;
+        int &x0u = q.x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
+        bool &none = q.none, &fits = q.fits, &interior = q.interior;
         // texel-space bounding box [lo, hi] of everything `nl` steps of every lane can touch; returns this lane's
         // "every step stays inside the volume (slab) with margin"
         auto chunk_box = [&](int nl, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
@@ -706,9 +686,6 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
             if (DIAG) ++st_retry;
         }
-#ifdef VRM_AB_ADAPT_KK
-        if (fits && !empty) kk_start = ((long long)nz * slice * 3 < (long long)CAP * 2) ? min((int)P.chunk_steps, kk + 1 + (kk >> 2)) : kk;
-#endif
         if (none) empty = true;
         else {
             if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
@@ -719,6 +696,50 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
             }
             if (SKIP) empty = box_is_empty();
         }
+        q.kk = kk;
+        q.empty = empty;
+    };
+    ChunkPlan cp;
+#ifdef VRM_LOOKAHEAD
+    ChunkPlan cp_next;
+    bool have_next = false;
+#endif
+    for (;;) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+#ifdef VRM_LOOKAHEAD
+        if (have_next) {
+            cp = cp_next;
+            have_next = false;
+        } else
+#endif
+        {
+            if (!DIAG && g.slab) {
+                // Slab-partitioned volume: this rank marches the whole volume's lattice but blends only its slab's samples.
+                // (The diagnostics build walks every step so that its per-ray counts stay those of the unpartitioned march.)
+                const float uz = __builtin_fmaf(dt, rs[2], bla[2]), dz = du[2], lo1 = g.u_lo[2] - 1.0f, hi1 = g.u_hi[2] + 1.0f; // one texel of margin
+                // past the slab and moving away: nothing left to blend, the accumulators are final
+                if (dz > 0.0f ? uz >= hi1 : (dz < 0.0f && uz < lo1)) active = false;
+                if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                // before the slab: advance the running dt sum up to the slab's entry plane without a chunk prologue per K
+                // steps (du carries 1 % slack, so the step count errs on the short side)
+                float ff = 0.0f;
+                if (dz > 0.0f && uz < lo1) ff = (lo1 - uz) / dz;
+                else if (dz < 0.0f && uz >= hi1) ff = (hi1 - uz) / dz;
+                const int nff = uni((int)fminf(wave_min(active ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
+                if (nff > 0) {
+                    advance_exact(dt, active, ray.t_max, nff);
+                    steps_left -= nff;
+                    active = active && steps_left > 0;
+                    continue;
+                }
+            }
+            plan(dt, active, steps_left, lvl, cp);
+        }
+        int &n_lane = cp.n_lane;
+        const int *ilo = cp.ilo;
+        const int nx = cp.nx, ny = cp.ny, nz = cp.nz, pitch = cp.pitch, slice = cp.slice, x0u = cp.x0u, kk = cp.kk;
+        const bool fits = cp.fits, interior = cp.interior;
+        bool empty = cp.empty;
         if (DIAG) ++st_chunks;
         if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
             lvl = 0;
@@ -766,6 +787,22 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
                                                              (__attribute__((address_space(3))) void *)(drow + ez * slice), 16, 0, 0);
                     }
                 }
+#ifdef VRM_LOOKAHEAD
+                // Look-ahead: while the box is in flight, plan the next chunk.  Without the early exit the state after this
+                // chunk's steps is known before they run (the dt lattice and the geometric end of the ray: advance_exact), and
+                // a staged chunk is followed by a plain one (lvl 0).  The plan's occupancy look-up queues behind the DMA.
+                if (!ERT && !DIAG && !g.slab) {
+                    float dt1 = dt;
+                    bool a1 = active;
+                    advance_exact(dt1, a1, ray.t_max, n_lane);
+                    const int sl1 = steps_left - n_lane;
+                    a1 = a1 && sl1 > 0;
+                    if (__builtin_amdgcn_ballot_w64(a1) != 0ull) {
+                        plan(dt1, a1, sl1, 0, cp_next);
+                        have_next = true;
+                    }
+                }
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 seen = 0xff000000u; // the staged texels do not pass through registers: emptiness comes from the occupancy grid alone
             } else {
