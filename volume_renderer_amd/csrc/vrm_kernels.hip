@@ -520,6 +520,11 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22; // per 2^-22 texel level
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
+    if (__builtin_amdgcn_ballot_w64(active) == 0ull) { // the tile misses the volume (half the tiles of a sphere view): clear colour
+        finish_colour<ALPHA_ONLY, USE_TF>(acc);
+        if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, 0u, 0u, 0u);
+        return;
+    }
 
     // Per-step advance of a ray in texel space.  The 1 % slack covers the drift of the running f32 dt sum (an ulp
     // of dt per step, 0.4 % of a step at dt = 100).
@@ -540,12 +545,12 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     // the tile's cross-section times the chunk depth whatever the entry geometry.  Which lane takes which step in
     // which chunk does not change any lane's own dt sequence: the image is bit-identical.
     // margin of the "interior chunk" test below: rounding of the one-FMA texel coordinate against the exact in-box test
-    // (as integer bounds on the chunk's box: the margin of the wave's worst lane, rounded outwards to whole texels)
+    // (as integer bounds on the chunk's box, rounded outwards to whole texels)
     int in_lo[3], in_hi[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        float e0 = 0.0f, eps = 0.021f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-        wave_minmax(e0, eps);
+        // (the ray origin is the camera position: the same for every lane)
+        const float eps = 0.021f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
         in_lo[a] = uni((int)ceilf(g.u_lo[a] + eps));
         in_hi[a] = uni((int)floorf(g.u_hi[a] - eps));
     }
