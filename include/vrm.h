@@ -194,6 +194,24 @@ VRM_API int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, ui
                                   size_t capacity_floats);
 VRM_API int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);
 
+/* ---- volume broadcast between the ranks of a view-partitioned export ---------------------
+ * No reference counterpart (the reference is one process on one adapter).  north_star: "the volume is broadcast once
+ * with RCCL over xGMI" -- for host programs that are not PyTorch (the Rust caller): one context per GPU and process,
+ * rank 0 makes an id and hands its 128 bytes to the other ranks by its own means (file, socket, MPI), every rank calls
+ * vrm_comm_init (a collective), every rank makes a grid of the same dimensions (vrm_grid_resize), the root uploads,
+ * everybody calls vrm_grid_broadcast: the root's RGBA8 voxels arrive in every context's grid (ncclBroadcast on the
+ * context's stream) and the receivers rebuild their bricks and occupancy pyramid.  RCCL is bound at first use (dlopen of
+ * librccl), so nothing else in the library depends on it; VRM_ERR_NO_DEVICE if it cannot be found.  The attenuation
+ * and the transfer function are 4 and 64 bytes: set them on every rank. */
+typedef struct vrm_comm_id {
+    uint8_t bytes[128]; /* an ncclUniqueId */
+} vrm_comm_id;
+VRM_API int vrm_comm_unique_id(vrm_comm_id *id);
+VRM_API int vrm_comm_init(vrm_ctx *ctx, const vrm_comm_id *id, int rank, int n_ranks);
+VRM_API int vrm_grid_broadcast(vrm_ctx *ctx, int root);
+/* also done by vrm_destroy */
+VRM_API int vrm_comm_destroy(vrm_ctx *ctx);
+
 /* ---- sort-last rendering of a z-slab-partitioned volume (no reference counterpart: ---------
  * ---- the reference holds the whole volume in one 3D texture, texture_3d.rs:22-80, state.rs:59) ---------- */
 

@@ -25,6 +25,10 @@ pub struct vrm_transfer_function {
 #[repr(C)] #[derive(Clone, Copy, Debug)]
 pub struct vrm_grid_uniform { pub dimensions: [u32; 4], pub box_min: [f32; 4], pub box_size: [f32; 4], pub buffer: [f32; 4] }
 
+/// an ncclUniqueId: made on rank 0 (vrm_comm_unique_id), carried to the other ranks by the caller's own means
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct vrm_comm_id { pub bytes: [u8; 128] }
+
 pub const VRM_OK: c_int = 0;
 pub const VRM_ERR_INVALID: c_int = -1;
 pub const VRM_ERR_NO_DEVICE: c_int = -2;
@@ -102,6 +106,11 @@ extern "C" {
     pub fn vrm_diag_read_counters(ctx: *mut vrm_ctx, out: *mut u64, reset: c_int) -> c_int;
     pub fn vrm_count_reference_samples(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, width: u32, height: u32,
                                        out_total: *mut u64) -> c_int;
+    // the volume broadcast of the view-partitioned export inside the library (RCCL, bound at first use); no reference counterpart
+    pub fn vrm_comm_unique_id(id: *mut vrm_comm_id) -> c_int;
+    pub fn vrm_comm_init(ctx: *mut vrm_ctx, id: *const vrm_comm_id, rank: c_int, n_ranks: c_int) -> c_int;
+    pub fn vrm_grid_broadcast(ctx: *mut vrm_ctx, root: c_int) -> c_int;
+    pub fn vrm_comm_destroy(ctx: *mut vrm_ctx) -> c_int;
     pub fn vrm_last_error() -> *const c_char;
     pub fn vrm_version() -> *const c_char;
 }

@@ -387,3 +387,35 @@ def test_netcdf4_hdf5_load(rm1, vr, orc, tmp_path):
         g = rm1.voxel_grid
         assert g.dimensions == (9, 10, 6) and list(g.uniform().buffer) == [1.0] * 4
         assert np.array_equal(g.download_rgba8(), orc.quantize_netcdf(data))
+
+
+def test_library_broadcast_single_rank(vr, orc):
+    """vrm_comm_* / vrm_grid_broadcast with RCCL bound inside the library.  One rank is all a one-GPU box can run (RCCL
+    refuses two ranks on one device): the id, the communicator, a broadcast in which this rank is the root, the
+    state checks; the image is unchanged.  Between different GPUs the call is unmeasured."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    r = vr.RayMarcher(0, 64, 64)
+    vox = synth.quantize_rgba8(synth.blobs_rgba_f32((24, 20, 28)))
+    r.voxel_grid.upload_rgba8(vox)
+    cam = vr.uniform_from_array(sphere_cam(orc, 2, 3))
+    img = vr.Screenshotter(r, 64, 64)
+    r.draw(cam, img)
+    before = img.read().copy()
+    with pytest.raises(vr.VrmError, match="no communicator"):
+        r.grid_broadcast(0)
+    cid = vr.RayMarcher.comm_unique_id()
+    assert len(cid) == 128 and any(cid)
+    r.comm_init(cid, 0, 1)
+    with pytest.raises(vr.VrmError, match="already has a communicator"):
+        r.comm_init(cid, 0, 1)
+    with pytest.raises(vr.VrmError, match="root"):
+        r.grid_broadcast(1)
+    r.grid_broadcast(0)
+    r.draw(cam, img)
+    assert np.array_equal(img.read(), before)
+    assert np.array_equal(r.voxel_grid.download_rgba8(), vox)
+    r.comm_destroy()
+    r.comm_destroy()          # idempotent
+    img.close()
+    r.close()

@@ -303,6 +303,25 @@ class RayMarcher:
         hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
         _ffi.check(_ffi.lib().vrm_draw_batch_static(self._h, cams, n, hs))
 
+    # -- the volume broadcast of a view-partitioned export inside the library (RCCL bound at first use; include/vrm.h) --
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes made on rank 0; hand them to the other ranks (file, socket, torch.distributed object broadcast ...)."""
+        buf = (ctypes.c_uint8 * 128)()
+        _ffi.check(_ffi.lib().vrm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, comm_id, rank, n_ranks):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(comm_id)
+        _ffi.check(_ffi.lib().vrm_comm_init(self._h, buf, int(rank), int(n_ranks)))
+
+    def grid_broadcast(self, root=0):
+        """Every rank holds a grid of the same dimensions; the root's voxels arrive in all of them."""
+        _ffi.check(_ffi.lib().vrm_grid_broadcast(self._h, int(root)))
+
+    def comm_destroy(self):
+        _ffi.check(_ffi.lib().vrm_comm_destroy(self._h))
+
     def draw_partial(self, camera_uniforms, width, height, device_ptr):
         """n views as premultiplied f32 RGBA into caller-owned device memory (n*H*W*4 floats); enqueue only.  For a slab
         grid (VoxelGrid.new_slab) this is the slab's partial image of a sort-last render."""

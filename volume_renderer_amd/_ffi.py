@@ -91,6 +91,10 @@ SYMBOLS = {
     "vrm_diag_read_counters": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "vrm_count_reference_samples": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]),
+    "vrm_comm_unique_id": (ctypes.c_int, [_vp]),
+    "vrm_comm_init": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "vrm_grid_broadcast": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vrm_comm_destroy": (ctypes.c_int, [_vp]),
     "vrm_load_netcdf": (ctypes.c_int, [_vp, ctypes.c_char_p]),
     "vrm_write_netcdf": (ctypes.c_int, [_vp, ctypes.c_char_p]),
     "vrm_netcdf_read_color": (ctypes.c_int, [ctypes.c_char_p, _u32p, _u32p, _u32p, _vp, ctypes.c_size_t]),

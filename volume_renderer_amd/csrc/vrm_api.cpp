@@ -7,6 +7,8 @@
 #include <mutex>
 #include <new>
 
+#include <dlfcn.h>
+
 #include "vrm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -246,6 +248,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
     // nothing of theirs is in flight any more; they keep their memory until vrm_image_destroy and refuse every other call
     for (vrm_image *img : ctx->images) img->ctx = nullptr;
     ctx->images.clear();
+    (void)vrm_comm_destroy(ctx);
     for (auto &p : ctx->prof_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -862,6 +865,116 @@ extern "C" int vrm_synchronize(vrm_ctx *ctx)
 }
 
 // ---- options / profiling ------------------------------------------------------------------------
+
+// ---- the one collective of the view-partitioned export, inside the library ----------------------------
+// RCCL is bound at first use (dlopen), so the library has no link-time dependency on it and a process that already holds
+// RCCL (PyTorch) shares that copy.  Only the four entry points used here are resolved.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;                                      // ncclGetUniqueId(ncclUniqueId*)
+    int (*CommInitRank)(void **, int, vrm_comm_id, int) = nullptr;             // ncclCommInitRank(comm*, n, id BY VALUE, rank)
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl q;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (q.lib) break;
+        }
+        if (!q.lib) {
+            q.why = std::string("RCCL not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")";
+            return q;
+        }
+        q.GetUniqueId = reinterpret_cast<decltype(q.GetUniqueId)>(dlsym(q.lib, "ncclGetUniqueId"));
+        q.CommInitRank = reinterpret_cast<decltype(q.CommInitRank)>(dlsym(q.lib, "ncclCommInitRank"));
+        q.Broadcast = reinterpret_cast<decltype(q.Broadcast)>(dlsym(q.lib, "ncclBroadcast"));
+        q.CommDestroy = reinterpret_cast<decltype(q.CommDestroy)>(dlsym(q.lib, "ncclCommDestroy"));
+        q.GetErrorString = reinterpret_cast<decltype(q.GetErrorString)>(dlsym(q.lib, "ncclGetErrorString"));
+        if (!q.GetUniqueId || !q.CommInitRank || !q.Broadcast || !q.CommDestroy) {
+            q.why = "RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclBroadcast / ncclCommDestroy";
+            q.lib = nullptr;
+        }
+        return q;
+    }();
+    return r;
+}
+int rccl_fail(const char *what, int code)
+{
+    Rccl &r = rccl();
+    vrm_set_error("%s failed: %s (RCCL result %d)", what, r.GetErrorString ? r.GetErrorString(code) : "?", code);
+    return VRM_ERR_HIP;
+}
+} // namespace
+
+extern "C" int vrm_comm_unique_id(vrm_comm_id *id)
+{
+    REQUIRE(id != nullptr, "null id");
+    Rccl &r = rccl();
+    if (!r.lib) {
+        vrm_set_error("%s", r.why.c_str());
+        return VRM_ERR_NO_DEVICE;
+    }
+    static_assert(sizeof(vrm_comm_id) == 128, "ncclUniqueId is 128 bytes");
+    const int e = r.GetUniqueId(id);
+    return e == 0 ? VRM_OK : rccl_fail("ncclGetUniqueId", e);
+}
+
+extern "C" int vrm_comm_init(vrm_ctx *ctx, const vrm_comm_id *id, int rank, int n_ranks)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    REQUIRE(id != nullptr, "null id");
+    REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
+    REQUIRE(ctx->comm == nullptr, "this context already has a communicator (vrm_comm_destroy first)");
+    Rccl &r = rccl();
+    if (!r.lib) {
+        vrm_set_error("%s", r.why.c_str());
+        return VRM_ERR_NO_DEVICE;
+    }
+    void *comm = nullptr;
+    const int e = r.CommInitRank(&comm, n_ranks, *id, rank); // collective: every rank of the job calls it
+    if (e != 0) return rccl_fail("ncclCommInitRank", e);
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_size = n_ranks;
+    return VRM_OK;
+}
+
+extern "C" int vrm_grid_broadcast(vrm_ctx *ctx, int root)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (ctx->comm == nullptr) {
+        vrm_set_error("no communicator: call vrm_comm_init on every rank first");
+        return VRM_ERR_STATE;
+    }
+    REQUIRE(root >= 0 && root < ctx->comm_size, "root %d outside the %d ranks", root, ctx->comm_size);
+    REQUIRE(ctx->vox != nullptr && ctx->vox_words != 0, "no grid");
+    REQUIRE(ctx->gdim[2] == ctx->dim[2], "a slab-partitioned grid is not replicated: nothing to broadcast");
+    // every rank must hold a grid of the same dimensions (vrm_grid_resize); the root's voxels replace the others' in place
+    const int e = rccl().Broadcast(ctx->vox, ctx->vox, ctx->vox_words * 4, /* ncclUint8 */ 1, root, ctx->comm, ctx->stream);
+    if (e != 0) return rccl_fail("ncclBroadcast", e);
+    if (ctx->comm_rank == root) return vrm_check_hip(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return grid_finish_upload(ctx); // bricks, packed alpha, occupancy pyramid, scalar detection of the received voxels
+}
+
+extern "C" int vrm_comm_destroy(vrm_ctx *ctx)
+{
+    REQUIRE(ctx != nullptr, "null context");
+    if (ctx->comm == nullptr) return VRM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    const int e = rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_size = 0;
+    return e == 0 ? VRM_OK : rccl_fail("ncclCommDestroy", e);
+}
 
 extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
 {

@@ -41,6 +41,10 @@ struct vrm_ctx {
     // later vrm_image_destroy frees their memory without touching the context's streams
     std::vector<struct vrm_image *> images;
 
+    // RCCL communicator of vrm_comm_init (an ncclComm_t; nullptr = none): the volume broadcast of the view-partitioned export
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
+
     // options
     int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1;
 
