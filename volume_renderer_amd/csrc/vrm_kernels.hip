@@ -587,6 +587,11 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     int lvl = 0, lvl_run = 0;
     const uint32_t lane_c0 = lane & 3u, lane_c1 = (lane >> 2) & 3u, lane_c2 = lane >> 4; // this lane's cell in an emptiness test
 
+    // Per-wave chunk depth.  How deep a box fits the tile depends on the view direction through this tile (an oblique
+    // tile's box is wide on all three axes): a box that had to be cut down sets the depth for the chunks that follow
+    // (no second box computation per chunk), and a box that leaves a fifth of the tile unused lets it grow by an eighth,
+    // up to 1.5x the launch's depth.  Chunking does not change the image (see the steps below).
+    int kk_base = (int)P.chunk_steps;
     // One chunk's plan: steps per lane, the box, how it lies in the tile, whether it is empty.  A function of the ray state
     // (dt, active, steps left) and the stride level alone, so it can be made for the NEXT chunk while the current chunk's
     // box is still in flight (look-ahead below).
@@ -598,7 +603,8 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
         for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(dt, rs[a], bla[a]);
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
-        int kk = (int)P.chunk_steps << lvl; // chunk length: the steps of the rear-most lane
+        // chunk length = the steps of the rear-most lane: the wave's learned depth for plain chunks, strides in empty space
+        int kk = lvl > 0 ? (int)P.chunk_steps << lvl : kk_base;
         int &n_lane = q.n_lane;      // steps of this lane in this chunk
         int *ilo = q.ilo, *ihi = q.ihi;
         int &nx = q.nx, &ny = q.ny, &nz = q.nz, &pitch = q.pitch, &slice = q.slice;
@@ -745,6 +751,10 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
         const int nx = cp.nx, ny = cp.ny, nz = cp.nz, pitch = cp.pitch, slice = cp.slice, x0u = cp.x0u, kk = cp.kk;
         const bool fits = cp.fits, interior = cp.interior;
         bool empty = cp.empty;
+        if (lvl == 0 && fits) {
+            if (kk < kk_base) kk_base = kk;
+            else if ((long long)nz * slice * 5 < (long long)CAP * 4 && 2 * kk_base < 3 * (int)P.chunk_steps) kk_base += max(1, kk_base >> 3);
+        }
         if (DIAG) ++st_chunks;
         if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
             lvl = 0;
