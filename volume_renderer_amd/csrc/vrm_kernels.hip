@@ -422,6 +422,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // skipping) and to bring a ray up to its rank's slab (sort-last): the iteration lattice is the oracle's, bit for bit.
 __device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_max, int n)
 {
+    {
+        // the usual case, decided for the whole wave: every lane's n steps are regular (same binade to the end, see below) and
+        // end short of t_max -- one FMA, nobody stops
+        const float d1 = dt + VRM_STEP_SIZE, inc = d1 - dt;
+        const float end = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, dt) & 0x7f800000u) + 0x00800000u);
+        const float reach = __builtin_fmaf((float)n, inc, dt); // exact when the steps are regular
+        const bool moves = active && n > 0;
+        const bool plain = dt >= 0x1p-8f && inc > 0.0f && (d1 + VRM_STEP_SIZE) - d1 == inc && reach + VRM_STEP_SIZE < end && reach < t_max;
+        if (__builtin_amdgcn_ballot_w64(moves && !plain) == 0ull) {
+            dt = moves ? reach : dt;
+            return;
+        }
+    }
     while (n > 0 && active) {
         const float d1 = dt + VRM_STEP_SIZE;
         const float inc = d1 - dt; // exact (Sterbenz)
