@@ -222,6 +222,28 @@ def test_batch_equals_single_draws(rm, vr, orc):
         im.close()
 
 
+def test_far_cameras_filter_at_the_oracle_sequence(rm, vr, orc):
+    """A camera hundreds of volume widths away: the camera position in texels (> 4096) makes the one-FMA texel coordinate
+    too coarse for the f32 contract on a noise volume, so such views are marched by the FAR instance of the kernel (the
+    oracle's own (ro + rd*dt)*scale + bias).  Same gates as everywhere else, and a batch that mixes near and far views
+    gives every view the image it gets alone."""
+    vox = synth.random_rgba8((130, 96, 65), 5)
+    configure(rm, vox, 40.0, True)
+    far = [orc.camera_uniform(orc.sphere_position(ix, iy, 8, 8, r)) for ix, iy, r in [(5, 2, 400.0), (1, 6, 100.0), (3, 3, 60.0)]]
+    for cam in far:
+        got = draw(rm, vr, cam, 96, 40)
+        check(orc, got, vox, cam, 96, 40, 40.0, True)
+    cams = [vr.uniform_from_array(c) for c in [sphere_cam(orc, 2, 3), far[0], sphere_cam(orc, 6, 5), far[1]]]
+    imgs = [vr.Screenshotter(rm, 72, 56) for _ in cams]
+    rm.draw_batch(cams, imgs)
+    batch = [im.read() for im in imgs]
+    for cam, im, want in zip(cams, imgs, batch):
+        rm.draw(cam, im)
+        assert np.array_equal(im.read(), want)
+    for im in imgs:
+        im.close()
+
+
 def test_parity_step_cap_on_a_long_volume(rm, vr, orc):
     """box_size = dims / min(dims) (grid.rs:268): a 4x4x48 volume is 12 units long, rays along z would need 12000 steps and
     stop at the 5000th iteration (wgsl:96,139) -- per lane, wherever the chunking put that step."""

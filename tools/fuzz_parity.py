@@ -83,11 +83,7 @@ def main():
             configure(rm, vox, att, tf)
             got = draw(rm, vr, cam, W, H)
             if att < 600.0:
-                # far cameras: the oracle's own sample position ro + rd*dt is rounded at the magnitude of ro (an ulp of 400 is
-                # 0.004 texel of a 130-texel volume) and the kernel's one-FMA texel coordinate carries a different error of
-                # the same size; the f32 gate widens in proportion, the 8-bit gates (<= 1 LSB, RMSE) stay as they are
-                far = float(np.linalg.norm(pos)) * max(dims) / 2.0e4
-                check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=max(1.0, far))
+                check(orc, got, vox, cam, W, H, att, tf)
             else:
                 # the exact `alpha >= 1.0` exit can fire (attenuation >= 693): WHEN it fires depends on the last ulp of a
                 # continuous quantity, so iteration counts may differ by a step; image and accumulators must still agree

@@ -4,7 +4,7 @@
 compiles vrm_kernels.hip with --save-temps into /tmp/isa and prints, per block, VALU / SALU / LDS / global counts and the
 branch targets: how the chunk prologue's VALU count in DESIGN.md 4.3 was obtained."""
 import re, subprocess, sys, os
-frag = sys.argv[1] if len(sys.argv) > 1 else "ILb0ELb0ELb0ELb1ELi2560ELb0ELb0E"
+frag = sys.argv[1] if len(sys.argv) > 1 else "ILb0ELb0ELb0ELb1ELi2560ELb0ELb0ELb0E"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",

@@ -8,6 +8,7 @@
 #include <new>
 
 #include <dlfcn.h>
+#include <math.h>
 
 #include "vrm_internal.h"
 
@@ -642,6 +643,16 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     p->packed_alpha = (int32_t)ctx->opt_packed;
 }
 
+// does the batch hold a view the FAR instance of the march kernel must take?  (The kernels decide per view at 4096 texels;
+// a lower bar here only means a launch whose waves all leave at once.)
+static uint32_t any_far_view(const VrmMarchParams &p, const vrm_camera_uniform *cameras, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a)
+            if (!(fabsf(fmaf(cameras[i].position[a], p.grid.tex_scale[a], p.grid.tex_bias[a])) <= 4000.0f)) return 1u;
+    return 0u;
+}
+
 static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets, bool use_static)
 {
     int rc = bind(ctx);
@@ -708,6 +719,7 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     VrmMarchParams p;
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, w, h, targets[0]->pitch);
+    p.any_far = any_far_view(p, cameras, n);
     p.views = dev_views;
     p.diag_counters = diag ? reinterpret_cast<unsigned long long *>(ctx->flag_dev + 16) : nullptr; // bytes 64..127 of the 256-byte scratch
 
@@ -782,6 +794,7 @@ extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras,
     VrmMarchParams p;
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, width, height, (size_t)width * 4);
+    p.any_far = any_far_view(p, cameras, n);
     p.views = ctx->views_dev + slot;
     HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, false, ctx->opt_skip != 0, ctx->stream));
     return VRM_OK;

@@ -470,7 +470,7 @@ struct ChunkPlan {
     bool none, fits, interior, empty;
 };
 
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
 #ifdef VRM_AB_LDS_PAD
 __global__ void __launch_bounds__(64, 2) march_lds_kernel
 #else
@@ -524,6 +524,16 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
     const bool in_image = px < P.width && py < P.height;
     const VrmViewDesc &v = P.views[view];
+    // Far cameras.  The texel coordinate u = dt*rs + bla cancels two terms of the size of bla (the camera position in
+    // texels): beyond 4096 texels an ulp of them is 0.0005 texel and the one-FMA coordinate drifts away from the oracle's
+    // (ro + rd*dt) * scale + bias by more than the f32 contract allows on high-contrast volumes.  Such views (hundreds of
+    // volume widths away) are marched by the FAR instance of this kernel, which filters at the oracle's own operation
+    // sequence -- still a function of dt alone, so every property of the chunking holds -- and gives its boxes the rounding
+    // of that sequence as extra slack.  Both instances see every view of a batch; each takes the views that are its own.
+    const float bla_max = fmaxf(fabsf(__builtin_fmaf(v.pos[0], g.tex_scale[0], g.tex_bias[0])),
+                                fmaxf(fabsf(__builtin_fmaf(v.pos[1], g.tex_scale[1], g.tex_bias[1])),
+                                      fabsf(__builtin_fmaf(v.pos[2], g.tex_scale[2], g.tex_bias[2]))));
+    if ((uni(bla_max > 4096.0f ? 1 : 0) != 0) != FAR) return; // view-uniform
     const Ray ray = setup_ray(v, g, in_image ? px : 0u, in_image ? py : 0u, P.width, P.height);
 
     Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -551,6 +561,17 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     float bla[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) bla[a] = __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]);
+    constexpr bool far_cam = FAR;
+    const float box_slack = 0.01f + (far_cam ? bla_max * 0x1p-20f : 0.0f);
+    auto texel_coord = [&](const float dtv, float u[3]) __attribute__((always_inline)) {
+        if (far_cam) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dtv, g.tex_scale[a], g.tex_bias[a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(dtv, rs[a], bla[a]);
+        }
+    };
     // Front alignment.  Rays start on the entry faces of the box, so "the same number of steps for every ray" keeps
     // the wave's samples on a copy of those faces: seen at a grazing angle an 8x8-pixel tile is spread over 40+
     // texels along the rays and no chunk ever fits the tile.  Instead the wave advances a plane perpendicular to its
@@ -610,10 +631,7 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     // box is still in flight (look-ahead below).
     auto plan = [&](const float dt, const bool active, const int steps_left, const int lvl, ChunkPlan &q) __attribute__((always_inline)) {
         float ua[3];
-#pragma unroll
-        // (the formula the samples are filtered at: the box below then holds their texels whatever the camera distance --
-        // the exact position ro + rd*dt, rounded at the magnitude of ro, differs from it by up to 0.06 texel at radius 1000)
-        for (int a = 0; a < 3; ++a) ua[a] = __builtin_fmaf(dt, rs[a], bla[a]);
+        texel_coord(dt, ua); // (the formula the samples are filtered at)
         const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
         // chunk length = the steps of the rear-most lane: the wave's learned depth for plain chunks, strides in empty space
@@ -644,8 +662,8 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 // (a wave without steps: +-inf clamp to +-2^28, an empty box)
-                const int li = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mn[a] - 0.01f, g.u_lo[a] - 0.5f, 0x1p28f)), 63);
-                const int hh = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mx[a] + 0.01f, -0x1p28f, g.u_hi[a])), 63) + 1;
+                const int li = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mn[a] - box_slack, g.u_lo[a] - 0.5f, 0x1p28f)), 63);
+                const int hh = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mx[a] + box_slack, -0x1p28f, g.u_hi[a])), 63) + 1;
                 // interior: min - 0.01 >= li >= in_lo >= u_lo + eps and max + 0.01 < hh <= in_hi <= u_hi - eps
                 inter = inter && li >= in_lo[a] && hh <= in_hi[a];
                 lo[a] = li;
@@ -935,9 +953,15 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
                         bool done = false;
                         if (inside) {
                             if (DIAG) { ++n_inside; ++n_exec; }
-                            const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
-                            const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
-                            const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
+                            float uu[3];
+                            if constexpr (FAR) {
+#pragma unroll
+                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+                            } else {
+#pragma unroll
+                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(dt, rs[a], bla[a]);
+                            }
+                            const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
@@ -989,9 +1013,9 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
                     if (inside) {
                         if (DIAG) { ++n_inside; ++n_exec; }
                         // the same filter coordinate as the staged path: which path a sample takes depends on the chunking
-                        const float u0 = __builtin_fmaf(dt, rs[0], bla[0]);
-                        const float u1 = __builtin_fmaf(dt, rs[1], bla[1]);
-                        const float u2 = __builtin_fmaf(dt, rs[2], bla[2]);
+                        float uu[3];
+                        texel_coord(dt, uu);
+                        const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
                         fetch_global(g, (int)f0, (int)f1, (int)f2, c);
@@ -1392,8 +1416,13 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
     do {                                                                                                          \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                      \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E>), grid, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E>), grid, block, 0, stream, p);       \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), grid, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false>), grid, block, 0, stream, p);       \
+        /* views of far-away cameras are left to the FAR instance (its waves take only those) */                  \
+        if (p.any_far) {                                                                                          \
+            if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, true, true>), grid, block, 0, stream, p);  \
+            else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, true, true>), grid, block, 0, stream, p);      \
+        }                                                                                                         \
     } while (0)
         // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU).  10 KB (16 waves per
         // CU) is the measured optimum for 256^3 .. 1024^3 volumes; variant 2 keeps the 8 KB tile (20 waves per CU, 5 per
