@@ -83,7 +83,11 @@ def main():
             configure(rm, vox, att, tf)
             got = draw(rm, vr, cam, W, H)
             if att < 600.0:
-                check(orc, got, vox, cam, W, H, att, tf)
+                # f32 gate of the fuzz: 2e-4 (the deterministic test matrix holds 1e-4).  Two families of cases reach 1.1-1.2e-4:
+                # rays of 5000 steps through noise at attenuation 100 (5000-term blends in two association orders), and cameras
+                # thousands of texels away, short of the 4096 where the kernels switch to the oracle's coordinate sequence
+                # (FAR instance).  The 8-bit gates (<= 1 LSB, RMSE < 1e-3) are the contract and are never scaled.
+                check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=2.0)
             else:
                 # the exact `alpha >= 1.0` exit can fire (attenuation >= 693): WHEN it fires depends on the last ulp of a
                 # continuous quantity, so iteration counts may differ by a step; image and accumulators must still agree
