@@ -750,7 +750,8 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
         // Issue priority by phase: a wave in its step loop goes before a wave that plans or stages (s_setprio 1 / 0).  The step
         // loops are what the SIMD's VALU is short of; a planning wave mostly waits on reductions and memory anyway.
-        // C3 0.367 -> 0.359 ms/view, C4 1.088 -> 1.057; the level (1..3) makes no difference, the other polarity loses.
+        // C3 0.367 -> 0.359 ms/view, C4 1.088 -> 1.057; the level (1..3) makes no difference, the other polarity loses, and so does
+        // raising the priority already for the staging loads (+1..2 %).
         __builtin_amdgcn_s_setprio(0);
 #ifdef VRM_LOOKAHEAD
         if (have_next) {
