@@ -277,8 +277,10 @@ VRM_API int vrm_png_read(const char *path, uint32_t *width, uint32_t *height, ui
 /* ---- build extensions (no reference counterpart) --------------------------------------------- */
 
 typedef enum vrm_option {
-    VRM_OPT_KERNEL = 0,       /* march kernel: 0 = global gathers (baseline), 1 = per-wave LDS staging, 10 KB tile (default),
-                                 2 = the same with an 8 KB tile, 5 waves per SIMD (tuning, DESIGN.md "Kernels") */
+    VRM_OPT_KERNEL = 0,       /* march kernel: 0 = global gathers (baseline), 1 = per-wave LDS staging, 10 KB tile (default; tiles handed
+                                 out through per-XCD queues or one workgroup per tile, whichever measured faster for the case),
+                                 2 = the same with an 8 KB tile, 5 waves per SIMD, 3 / 4 = variant 1 with queues / workgroups
+                                 forced (tuning, DESIGN.md "Kernels"); the image does not depend on 1..4 */
     VRM_OPT_SKIP_EMPTY = 1,   /* exact empty-space skipping, default 1: chunks whose texels all have alpha == 0 are not
                                  sampled; they contribute exactly 0, so the image is bit-identical to 0 (tests) */
     VRM_OPT_PROFILE = 2,      /* default 0; 1: record hipEvents around every march launch (vrm_profile_read) */

@@ -72,7 +72,7 @@ def main():
         if np.allclose(pos, tgt) or abs(np.cross(np.subtract(tgt, pos), (0, 1, 0))).max() < 1e-3:
             continue                                    # look direction parallel to the up vector: degenerate basis
         cam = orc.camera_uniform(pos, target=tgt, aspect=W / H)
-        opts = {vr.OPT_KERNEL: int(rng.choice([0, 1, 1, 1, 2, 2])), vr.OPT_SKIP_EMPTY: int(rng.integers(0, 2)),
+        opts = {vr.OPT_KERNEL: int(rng.choice([0, 1, 1, 1, 2, 2, 3, 4])), vr.OPT_SKIP_EMPTY: int(rng.integers(0, 2)),
                 vr.OPT_PACKED_ALPHA: int(rng.integers(0, 2)), vr.OPT_CHUNK_STEPS: int(rng.choice([0, 0, 1, 3, 40]))}
         for k, v in opts.items():
             rm.set_option(k, v)

@@ -224,6 +224,7 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
         if ((rc = scratch_init(ctx->device, &ctx->scratch))) break; // this device's copy of the static descriptor scratch
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMemsetAsync(ctx->flag_dev, 0, 256, ctx->stream), "hipMemsetAsync"))) break;
+        if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->queue_dev, 1024), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
                                 "hipHostMalloc")))
@@ -259,6 +260,7 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
     if (ctx->bricks) (void)hipFree(ctx->bricks);
     if (ctx->abricks) (void)hipFree(ctx->abricks);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
     if (ctx->views_dev) (void)hipFree(ctx->views_dev);
     if (ctx->views_host) (void)hipHostFree(ctx->views_host);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -641,6 +643,7 @@ static void fill_params(const vrm_ctx *ctx, VrmMarchParams *p, uint32_t w, uint3
     p->use_tf = ctx->tf.use_transfer_function[0] != 0 ? 1u : 0u;
     p->chunk_steps = (uint32_t)ctx->opt_chunk;
     p->packed_alpha = (int32_t)ctx->opt_packed;
+    p->queue = ctx->opt_kernel == 4 ? nullptr : ctx->queue_dev; // (4: one workgroup per tile whatever the launcher would choose)
 }
 
 // does the batch hold a view the FAR instance of the march kernel must take?  (The kernels decide per view at 4096 texels;

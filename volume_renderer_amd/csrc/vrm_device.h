@@ -66,6 +66,11 @@ struct VrmMarchParams {
     float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
     uint32_t use_tf;
     uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 8 texels of depth)
+    // tile queues of the march kernel (nullptr: one workgroup per tile and view): 8 counters, 128 bytes apart, zeroed by the
+    // launcher; n_views = the views of this launch
+    uint32_t *queue;
+    uint32_t n_views;
+    uint32_t tiles_total(uint32_t views) const { return sblocks_x * sblocks_y * 64u * views; }
     uint32_t any_far;     // some view of the batch may be a far-camera view (|camera in texels| > 4096): launch the FAR instance too
     int32_t packed_alpha; // 1-channel march staged from the packed alpha bricks (default) or, 0, from the RGBA8 bricks
     // diagnostics build only (else nullptr): 8 counters the waves add to -- filtered samples, of those with alpha exactly 0,

@@ -29,6 +29,7 @@ struct vrm_ctx {
     float attenuation = 1.0f;
     vrm_transfer_function tf;
     uint32_t *flag_dev = nullptr; // 1 word scratch for detect_nonscalar
+    uint32_t *queue_dev = nullptr; // 1 KB: the march kernel's tile-queue counters (8, 128 bytes apart)
 
     // batch descriptors (device + pinned staging)
     VrmViewDesc *views_dev = nullptr;

@@ -470,13 +470,9 @@ struct ChunkPlan {
     bool none, fits, interior, empty;
 };
 
+// One 8x8-pixel tile of one view, marched by one wave: `xcd` and `slot` say which (see "Tile order" below).
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
-#ifdef VRM_AB_LDS_PAD
-__global__ void __launch_bounds__(64, 2) march_lds_kernel
-#else
-__global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel
-#endif
-(const VrmMarchParams P)
+__device__ __forceinline__ void march_tile(const VrmMarchParams &P, const uint32_t view, const uint32_t xcd, const uint32_t slot)
 {
     // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
     // four x-adjacent texels instead of one RGBA8 texel: a quarter of the staging bytes and of the tile's x extent.
@@ -491,29 +487,12 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     __shared__ __attribute__((aligned(16))) uint32_t tile[CAP];
 #endif
     const VrmGridDev &g = P.grid;
-#ifdef VRM_AB_VIEW_INTERLEAVE
-    // A/B experiment (DESIGN.md 4.3, C4 staging): VRM_AB_VIEW_INTERLEAVE consecutive views of the launch advance through
-    // the image together (dispatch order: tile slot, then view within the group) instead of one view after the other
-    const uint32_t per_view = gridDim.x >> 3;                        // tile slots of one view on one XCD
-    const uint32_t q_ = (blockIdx.x >> 3) + per_view * blockIdx.y;   // this workgroup's position in its XCD's dispatch order
-    const uint32_t grp_ = q_ / (VRM_AB_VIEW_INTERLEAVE * per_view), r_ = q_ - grp_ * (VRM_AB_VIEW_INTERLEAVE * per_view);
-    const uint32_t view = grp_ * VRM_AB_VIEW_INTERLEAVE + r_ % VRM_AB_VIEW_INTERLEAVE;
-    if (view >= gridDim.y) return;
-    const uint32_t slot_ab = r_ / VRM_AB_VIEW_INTERLEAVE;
-#else
-    const uint32_t view = blockIdx.y;
-#endif
     // Tile order.  The image is cut into 64x64-pixel super-blocks (8x8 wave tiles).  Workgroup b runs on the
     // XCD group b % 8 (hardware round-robin); that group owns the super-blocks on the diagonals
     // (sbx + sby) % 8 == b % 8 and walks through them one after the other.  So the ~320 waves an XCD has in
     // flight cover a few compact image patches (=> a compact part of the volume in its L2), while every XCD
     // gets the same mix of centre (long rays) and border (misses) super-blocks: the in-order dispatcher
     // stalls on the slowest XCD, so balance matters more than anything else here.
-#ifdef VRM_AB_VIEW_INTERLEAVE
-    const uint32_t xcd = blockIdx.x & 7u, slot = slot_ab;
-#else
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-#endif
     const uint32_t j = slot >> 6, within = slot & 63u;
     const uint32_t per_row = P.sblocks_x >> 3;             // sblocks_x is padded to a multiple of 8
     const uint32_t sby = j / per_row, m = j - sby * per_row;
@@ -1058,6 +1037,46 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     }
 }
 
+// The march kernel: one wave per workgroup.  Two ways of handing out the tiles:
+//  * one workgroup per tile and view (grid = tiles x views), dealt to the XCDs round-robin by the dispatcher, or
+//  * P.queue != nullptr: as many workgroups as the chip holds, each taking tiles from its XCD's queue -- the same order,
+//    (view, slot) = position q in the XCD's list, claimed with one atomic per tile -- and, once that queue is empty, from
+//    the other XCDs' queues.  No workgroup waits behind another XCD's slow tiles (the hardware dispatcher hands workgroups
+//    out in order) and the launch has no tail in which most of the chip idles.  Every wave leaves when all eight queues
+//    are empty; a tile is marched exactly once whichever wave claims it, so the image does not depend on the mode.
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
+#ifdef VRM_AB_LDS_PAD
+__global__ void __launch_bounds__(64, 2) march_lds_kernel
+#else
+__global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel
+#endif
+(const VrmMarchParams P)
+{
+    if (P.queue == nullptr) {
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, blockIdx.y, blockIdx.x & 7u, blockIdx.x >> 3);
+        return;
+    }
+    const uint32_t per_view = P.sblocks_x * P.sblocks_y * 8u; // tile slots of one view in one XCD's list
+    const uint32_t total = per_view * P.n_views;
+    uint32_t xcd = blockIdx.x & 7u;
+    // (Measured and dropped: claims of several tiles at once, +5 % for two and +40 % for eight -- what the L2 likes is
+    // neighbouring tiles marched at the same time by neighbouring waves, not one after the other by one wave; a claim
+    // issued one tile ahead to hide its latency, +5 % for the same reason; counters kept in the XCD's own L2 without
+    // helping other XCDs, which gives the whole gain back: the gain IS the balance between XCDs.)
+    for (uint32_t tried = 0; tried < 8u;) {
+        uint32_t q = 0;
+        if (threadIdx.x == 0) q = atomicAdd(&P.queue[xcd * 32u], 1u); // (counters 128 bytes apart)
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        if (q >= total) { // this list is done: help with the next XCD's
+            ++tried;
+            xcd = (xcd + 1u) & 7u;
+            continue;
+        }
+        const uint32_t view = q / per_view;
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, view, xcd, q - view * per_view);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reference-equivalent sample count: the number of loop iterations raymarch() (wgsl:139-187) executes
 // for every ray of a view when the early exit `alpha >= 1.0` does not fire (it cannot for
@@ -1407,9 +1426,19 @@ inline uint32_t stream_blocks(size_t n)
     return (uint32_t)(b < cap ? (b ? b : 1) : cap);
 }
 
+inline uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// one-wave workgroups the current device holds at once with `lds_bytes` of LDS each (160 KB per CU on gfx950)
+inline uint32_t resident_waves(uint32_t lds_bytes)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (uint32_t)cus * (160u * 1024u / lds_bytes);
+}
+
 template <bool A, bool T, bool D, bool E>
 void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, hipStream_t stream)
 {
+    p.n_views = n_views;
     if (variant == 0) {
         const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
@@ -1422,12 +1451,19 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
     do {                                                                                                          \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                      \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), grid, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false>), grid, block, 0, stream, p);       \
+        /* tile queues: as many one-wave workgroups as the chip holds at CAPV words of LDS each.  Variant 1 chooses:     \
+         * queues balance the XCDs (C3 -7 %, small images up to -44 %) but expose one atomic round trip per tile, which   \
+         * costs the packed march of large images more than it gains (+6 % at 1024^2, +9 % at 1536^2). */               \
+        if (variant == 1 && (PK) && skip && p.sblocks_x * p.sblocks_y * 64u > 12288u) p.queue = nullptr;                \
+        const dim3 gridq(p.queue ? min_u32(p.tiles_total(n_views), resident_waves((CAPV) * 4u)) : grid.x, p.queue ? 1u : grid.y, 1); \
+        if (p.queue) (void)hipMemsetAsync(p.queue, 0, 1024, stream);                                               \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), gridq, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false>), gridq, block, 0, stream, p);       \
         /* views of far-away cameras are left to the FAR instance (its waves take only those) */                  \
         if (p.any_far) {                                                                                          \
-            if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, true, true>), grid, block, 0, stream, p);  \
-            else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, true, true>), grid, block, 0, stream, p);      \
+            if (p.queue) (void)hipMemsetAsync(p.queue, 0, 1024, stream);                                           \
+            if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, true, true>), gridq, block, 0, stream, p);  \
+            else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, true, true>), gridq, block, 0, stream, p);      \
         }                                                                                                         \
     } while (0)
         // (LDS words per wave, box depth in texels): LDS per wave sets the waves per CU (160 KB / CU).  10 KB (16 waves per
