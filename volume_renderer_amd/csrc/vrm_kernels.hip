@@ -1455,6 +1455,8 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
          * queues balance the XCDs (C3 -7 %, small images up to -44 %) but expose one atomic round trip per tile, which   \
          * costs the packed march of large images more than it gains (+6 % at 1024^2, +9 % at 1536^2). */               \
         if (variant == 1 && (PK) && skip && p.sblocks_x * p.sblocks_y * 64u > 12288u) p.queue = nullptr;                \
+        /* ... and a launch of one or two views is over before the balance matters (1 view: 0.74 vs 0.79 ms at 1024^2) */ \
+        if (variant == 1 && n_views < 3u) p.queue = nullptr;                                                       \
         const dim3 gridq(p.queue ? min_u32(p.tiles_total(n_views), resident_waves((CAPV) * 4u)) : grid.x, p.queue ? 1u : grid.y, 1); \
         if (p.queue) (void)hipMemsetAsync(p.queue, 0, 1024, stream);                                               \
         if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), gridq, block, 0, stream, p);   \
