@@ -224,7 +224,7 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
         if ((rc = scratch_init(ctx->device, &ctx->scratch))) break; // this device's copy of the static descriptor scratch
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMemsetAsync(ctx->flag_dev, 0, 256, ctx->stream), "hipMemsetAsync"))) break;
-        if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->queue_dev, 1024), "hipMalloc"))) break;
+        if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->queue_dev, VRM_QUEUE_BYTES), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
                                 "hipHostMalloc")))

@@ -6,6 +6,8 @@
 
 #define VRM_MAX_STEP_AMOUNT 5000 /* raymarcher.wgsl:96 */
 #define VRM_STEP_SIZE 0.001f     /* raymarcher.wgsl:126 */
+#define VRM_QUEUE_SUBS 4         /* counters per XCD list of the march kernel's tile queues */
+#define VRM_QUEUE_BYTES (8 * VRM_QUEUE_SUBS * 128) /* the counters, 128 bytes apart */
 #define VRM_OCC_LEVELS 4         /* levels of the occupancy max pyramid (cells of 4, 8, 16, 32 texels) */
 
 // One entry per view of a batch, resident in device memory (read through the scalar cache).
@@ -66,7 +68,7 @@ struct VrmMarchParams {
     float col_a[3], col_b[3], col_c[3]; // transfer function colours (grid.rs:285-287)
     uint32_t use_tf;
     uint32_t chunk_steps; // variant 1+: march steps per staged box; 0 = let the launcher choose (about 8 texels of depth)
-    // tile queues of the march kernel (nullptr: one workgroup per tile and view): 8 counters, 128 bytes apart, zeroed by the
+    // tile queues of the march kernel (nullptr: one workgroup per tile and view): 8 x VRM_QUEUE_SUBS counters, 128 bytes apart, zeroed by the
     // launcher; n_views = the views of this launch
     uint32_t *queue;
     uint32_t n_views;

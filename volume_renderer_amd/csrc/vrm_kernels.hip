@@ -1063,13 +1063,23 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     // neighbouring tiles marched at the same time by neighbouring waves, not one after the other by one wave; a claim
     // issued one tile ahead to hide its latency, +5 % for the same reason; counters kept in the XCD's own L2 without
     // helping other XCDs, which gives the whole gain back: the gain IS the balance between XCDs.)
-    for (uint32_t tried = 0; tried < 8u;) {
-        uint32_t q = 0;
-        if (threadIdx.x == 0) q = atomicAdd(&P.queue[xcd * 32u], 1u); // (counters 128 bytes apart)
-        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-        if (q >= total) { // this list is done: help with the next XCD's
+    // Each list is claimed through VRM_QUEUE_SUBS counters, counter s handing out the tiles of the list's super-blocks s,
+    // s + SUBS, ... one super-block after the other: atomics on one address complete one after the other, and four counters
+    // are worth 1 % on C3 and 4 % on the packed march (more counters, or counters interleaved tile by tile instead of
+    // super-block by super-block, lose it again: the waves on one counter should be enough to march a super-block's tiles
+    // at about the same time).
+    uint32_t sub = (blockIdx.x >> 3) % VRM_QUEUE_SUBS;
+    for (uint32_t tried = 0; tried < 8u * VRM_QUEUE_SUBS;) {
+        uint32_t c = 0;
+        if (threadIdx.x == 0) c = atomicAdd(&P.queue[(xcd * VRM_QUEUE_SUBS + sub) * 32u], 1u); // (counters 128 bytes apart)
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        const uint32_t q = (((c >> 6) * VRM_QUEUE_SUBS + sub) << 6) + (c & 63u);
+        if (q >= total) { // this counter's super-blocks are done: the next counter, after the last one the next XCD's list
             ++tried;
-            xcd = (xcd + 1u) & 7u;
+            if (++sub == VRM_QUEUE_SUBS) {
+                sub = 0;
+                xcd = (xcd + 1u) & 7u;
+            }
             continue;
         }
         const uint32_t view = q / per_view;
@@ -1458,12 +1468,12 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         /* ... and a launch of one or two views is over before the balance matters (1 view: 0.74 vs 0.79 ms at 1024^2) */ \
         if (variant == 1 && n_views < 3u) p.queue = nullptr;                                                       \
         const dim3 gridq(p.queue ? min_u32(p.tiles_total(n_views), resident_waves((CAPV) * 4u)) : grid.x, p.queue ? 1u : grid.y, 1); \
-        if (p.queue) (void)hipMemsetAsync(p.queue, 0, 1024, stream);                                               \
+        if (p.queue) (void)hipMemsetAsync(p.queue, 0, VRM_QUEUE_BYTES, stream);                                               \
         if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), gridq, block, 0, stream, p);   \
         else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false>), gridq, block, 0, stream, p);       \
         /* views of far-away cameras are left to the FAR instance (its waves take only those) */                  \
         if (p.any_far) {                                                                                          \
-            if (p.queue) (void)hipMemsetAsync(p.queue, 0, 1024, stream);                                           \
+            if (p.queue) (void)hipMemsetAsync(p.queue, 0, VRM_QUEUE_BYTES, stream);                                           \
             if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, true, true>), gridq, block, 0, stream, p);  \
             else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, true, true>), gridq, block, 0, stream, p);      \
         }                                                                                                         \
