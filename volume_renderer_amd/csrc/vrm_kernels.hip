@@ -472,7 +472,7 @@ struct ChunkPlan {
 
 // One 8x8-pixel tile of one view, marched by one wave: `xcd` and `slot` say which (see "Tile order" below).
 template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
-__device__ __forceinline__ void march_tile(const VrmMarchParams &P, const uint32_t view, const uint32_t xcd, const uint32_t slot)
+__device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmViewDesc &v, const uint32_t xcd, const uint32_t slot)
 {
     // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
     // four x-adjacent texels instead of one RGBA8 texel: a quarter of the staging bytes and of the tile's x extent.
@@ -502,7 +502,6 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const uint32
     const uint32_t lane = threadIdx.x;
     const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
     const bool in_image = px < P.width && py < P.height;
-    const VrmViewDesc &v = P.views[view];
     // Far cameras.  The texel coordinate u = dt*rs + bla cancels two terms of the size of bla (the camera position in
     // texels): beyond 4096 texels an ulp of them is 0.0005 texel and the one-FMA coordinate drifts away from the oracle's
     // (ro + rd*dt) * scale + bias by more than the f32 contract allows on high-contrast volumes.  Such views (hundreds of
@@ -1053,7 +1052,7 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
 (const VrmMarchParams P)
 {
     if (P.queue == nullptr) {
-        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, blockIdx.y, blockIdx.x & 7u, blockIdx.x >> 3);
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, P.views[blockIdx.y], blockIdx.x & 7u, blockIdx.x >> 3);
         return;
     }
     const uint32_t per_view = P.sblocks_x * P.sblocks_y * 8u; // tile slots of one view in one XCD's list
@@ -1083,7 +1082,7 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
             continue;
         }
         const uint32_t view = q / per_view;
-        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, view, xcd, q - view * per_view);
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, P.views[view], xcd, q - view * per_view);
     }
 }
 
