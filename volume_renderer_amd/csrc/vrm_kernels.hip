@@ -1060,7 +1060,7 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     uint32_t xcd = blockIdx.x & 7u;
     // (Measured and dropped: claims of several tiles at once, +5 % for two and +40 % for eight -- what the L2 likes is
     // neighbouring tiles marched at the same time by neighbouring waves, not one after the other by one wave; a claim
-    // issued one tile ahead to hide its latency, +5 % for the same reason; counters kept in the XCD's own L2 without
+    // issued one tile ahead to hide its latency, +5 % for the same reason, and 0 % when issued only in a tile's last chunks; counters kept in the XCD's own L2 without
     // helping other XCDs, which gives the whole gain back: the gain IS the balance between XCDs.)
     // Each list is claimed through VRM_QUEUE_SUBS counters, counter s handing out the tiles of the list's super-blocks s,
     // s + SUBS, ... one super-block after the other: atomics on one address complete one after the other, and four counters
