@@ -1466,6 +1466,8 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         if (variant == 1 && (PK) && skip && p.sblocks_x * p.sblocks_y * 64u > 12288u) p.queue = nullptr;                \
         /* ... and a launch of one or two views is over before the balance matters (1 view: 0.74 vs 0.79 ms at 1024^2) */ \
         if (variant == 1 && n_views < 3u) p.queue = nullptr;                                                       \
+        /* (queue positions are 32-bit: a launch of 2^32 tiles or more, which no image memory holds, keeps the grid form) */ \
+        if ((uint64_t)p.sblocks_x * p.sblocks_y * 64u * n_views >= (1ull << 32)) p.queue = nullptr;                \
         const dim3 gridq(p.queue ? min_u32(p.tiles_total(n_views), resident_waves((CAPV) * 4u)) : grid.x, p.queue ? 1u : grid.y, 1); \
         if (p.queue) (void)hipMemsetAsync(p.queue, 0, VRM_QUEUE_BYTES, stream);                                               \
         if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), gridq, block, 0, stream, p);   \
