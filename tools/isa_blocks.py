@@ -2,14 +2,14 @@
 """Static instruction counts per basic block of one march_lds_kernel instantiation (run here, on the CPU):
     python tools/isa_blocks.py [mangled-template-fragment]      default: the C3 production kernel
 compiles vrm_kernels.hip with --save-temps into /tmp/isa and prints, per block, VALU / SALU / LDS / global counts and the
-branch targets: how the chunk prologue's VALU count in DESIGN.md 4.3 was obtained."""
+branch targets: how the chunk prologue's VALU count in DESIGN.md 4.3 was obtained.  ISA_FLAGS="-DVRM_...=..." adds compiler flags."""
 import re, subprocess, sys, os
 frag = sys.argv[1] if len(sys.argv) > 1 else "ILb0ELb0ELb0ELb1ELi2560ELb0ELb0ELb0E"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-rdc", "-fvisibility=hidden", "-I" + root + "/include",
-                       "--save-temps", "-c", root + "/volume_renderer_amd/csrc/vrm_kernels.hip", "-o", "k.o"], cwd="/tmp/isa",
+                       "--save-temps", *os.environ.get("ISA_FLAGS", "").split(), "-c", root + "/volume_renderer_amd/csrc/vrm_kernels.hip", "-o", "k.o"], cwd="/tmp/isa",
                       stderr=subprocess.DEVNULL)
 lines = open("/tmp/isa/vrm_kernels-hip-amdgcn-amd-amdhsa-gfx950.s").read().split("\n")
 name = frag if "kernel" in frag else "march_lds_kernel" + frag   # e.g. march_wg_kernelILb0ELb0ELb1ELi6144ELb0ELb0E

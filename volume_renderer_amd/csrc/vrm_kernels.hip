@@ -126,12 +126,34 @@ struct Accum {
     float cr, cg, cb, alpha; // colour in 0..255 texel units while marching when the TF is off
 };
 
+// The transfer function's three colours, held in VGPRs on purpose: the march kernel is short of SGPRs, and nine uniform
+// floats that every sample reads were what the register allocator spilled to VGPR lanes and read back per sample
+// (v_readlane + v_mov in the step loop).  As vector registers they feed v_cndmask directly.
+struct TfRegs {
+    float a[3], b[3], c[3];
+};
+template <bool USE_TF>
+__device__ __forceinline__ TfRegs tf_regs(const VrmMarchParams &P)
+{
+    TfRegs t = {};
+    if (USE_TF) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t.a[i] = P.col_a[i];
+            t.b[i] = P.col_b[i];
+            t.c[i] = P.col_c[i];
+            asm volatile("" : "+v"(t.a[i]), "+v"(t.b[i]), "+v"(t.c[i]));
+        }
+    }
+    return t;
+}
+
 // Trilinear filter of the 8 corner texels (c[z][y][x] as RGBA8 words) + transfer function (wgsl:145-147)
 // + Beer-Lambert opacity (wgsl:150) + front-to-back blend (wgsl:158-159).  Returns alpha >= 1 (wgsl:176).
 // Filter arithmetic runs in units of 2^-22 texel levels (see byte_scaled): `a22` below is the filtered alpha in those units,
 // kexp22 = kexp * 2^22 / 255... folded by the caller so that a22 * kexp22 = -a * step * attenuation * log2(e).
 template <bool ALPHA_ONLY, bool USE_TF, bool ERT>
-__device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp22, const VrmMarchParams &P,
+__device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, float wz, float kexp22, const TfRegs &P,
                                       Accum &acc, float *a_out = nullptr)
 {
     // Byte k of an RGBA8 word read through SDWA is the f32 denormal k * 2^-149: one instruction gives the difference
@@ -161,9 +183,9 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         const float a = a22 * (T22 * (1.0f / 255.0f));
         const bool hi = a >= 0.5f;
         const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
-        const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
-        const float s1 = hi ? P.col_b[1] : P.col_a[1], e1 = hi ? P.col_c[1] : P.col_b[1];
-        const float s2 = hi ? P.col_b[2] : P.col_a[2], e2 = hi ? P.col_c[2] : P.col_b[2];
+        const float s0 = hi ? P.b[0] : P.a[0], e0 = hi ? P.c[0] : P.b[0];
+        const float s1 = hi ? P.b[1] : P.a[1], e1 = hi ? P.c[1] : P.b[1];
+        const float s2 = hi ? P.b[2] : P.a[2], e2 = hi ? P.c[2] : P.b[2];
         acc.cr = __builtin_fmaf(w, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
         acc.cg = __builtin_fmaf(w, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
         acc.cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
@@ -185,7 +207,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
 // The 1-channel march from the packed alpha copy (VrmGridDev::abricks): w[i] holds texel x of row i in byte 0 and
 // texel x+1 in byte 1 (rows: y0z0, y1z0, y0z1, y1z1).  Same arithmetic on the same values as shade<true, USE_TF>.
 template <bool USE_TF, bool ERT>
-__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp22, const VrmMarchParams &P,
+__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp22, const TfRegs &P,
                                              Accum &acc, float *a_out = nullptr)
 {
     const float wxs = wx * 0x1p127f;
@@ -206,9 +228,9 @@ __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, floa
         const float a = a22 * (T22 * (1.0f / 255.0f));
         const bool hi = a >= 0.5f;
         const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
-        const float s0 = hi ? P.col_b[0] : P.col_a[0], e0 = hi ? P.col_c[0] : P.col_b[0];
-        const float s1 = hi ? P.col_b[1] : P.col_a[1], e1 = hi ? P.col_c[1] : P.col_b[1];
-        const float s2 = hi ? P.col_b[2] : P.col_a[2], e2 = hi ? P.col_c[2] : P.col_b[2];
+        const float s0 = hi ? P.b[0] : P.a[0], e0 = hi ? P.c[0] : P.b[0];
+        const float s1 = hi ? P.b[1] : P.a[1], e1 = hi ? P.c[1] : P.b[1];
+        const float s2 = hi ? P.b[2] : P.a[2], e2 = hi ? P.c[2] : P.b[2];
         acc.cr = __builtin_fmaf(wgt, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
         acc.cg = __builtin_fmaf(wgt, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
         acc.cb = __builtin_fmaf(wgt, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
@@ -295,6 +317,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
     uint32_t iters = 0, n_inside = 0;
     if (ray.hit) {
         const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22;
+        const TfRegs tf = tf_regs<USE_TF>(P);
         float dt = ray.t_min;
         for (int i = 0; i < VRM_MAX_STEP_AMOUNT; ++i) {
             ++iters;
@@ -312,7 +335,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
                 const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                 uint32_t c[8];
                 fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                if (shade<ALPHA_ONLY, USE_TF, true>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc)) break; // wgsl:176-178
+                if (shade<ALPHA_ONLY, USE_TF, true>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc)) break; // wgsl:176-178
             }
             dt += VRM_STEP_SIZE;          // wgsl:181, running f32 sum
             if (dt >= ray.t_max) break;   // wgsl:184-186
@@ -519,6 +542,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // diagnostics build: per-lane count of filtered samples whose alpha came out exactly 0, and per-wave chunk statistics
     uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0, st_retry = 0;
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22; // per 2^-22 texel level
+    const TfRegs tf = tf_regs<USE_TF>(P);
     bool active = in_image && ray.hit;
     float dt = ray.t_min;
     if (__builtin_amdgcn_ballot_w64(active) == 0ull) { // the tile misses the volume (half the tiles of a sphere view): clear colour
@@ -591,6 +615,45 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     }
     const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
     const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
+    // Boxes from the tile's geometry.  The rays of a tile are a pencil through the camera: at plane coordinate p (along the
+    // major axis, see `prog` below) lane l is at u_a = bla_a + (p - p_cam) * B_l[a], B_l[a] = rs_l[a] / |rs_l[m]|, and a
+    // chunk's samples lie between the plane of the rear-most lane and the plane the chunk ends at.  With the extremes of B
+    // over the tile's rays (reduced ONCE per tile) the box of a chunk is six fused multiply-adds on wave-uniform numbers --
+    // lane 2a holds the lower bound of axis a, lane 2a+1 the upper -- instead of a six-chain reduction over the lanes' own
+    // first and last positions per chunk.  A bound, not the hull: lanes that have ended still count, and the rounding of
+    // this formula against the samples' own u(dt) (about 1e-3 texel at 4096 texels from the camera) is covered by the slack.
+#ifndef VRM_GEO_BOX
+#define VRM_GEO_BOX 1
+#endif
+    constexpr bool GEO = VRM_GEO_BOX != 0 && !FAR;
+    // (All of it lives in VGPRs -- the kernel is short of SGPRs: geo_bn / geo_bf are the slope B where the near / the far
+    // plane gives this lane's bound and 0 where the other one does, geo_c the bound at p = 0 with the slack, p_cam the
+    // camera's plane coordinate, +inf where this path is off.)
+    float geo_bn = 0.0f, geo_bf = 0.0f, geo_c = 0.0f, geo_cl = 0.0f, geo_ch = 0.0f, p_cam = __builtin_inff();
+    if (GEO && aligned) {
+        const float inv_m = sgn / (m_axis == 0 ? rs[0] : m_axis == 1 ? rs[1] : rs[2]); // 1 / |rs_m|: every active lane moves forward
+        float bmn[3], bmx[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float b = rs[a] * inv_m;
+            bmn[a] = active ? b : __builtin_inff();
+            bmx[a] = active ? b : -__builtin_inff();
+            wave_minmax(bmn[a], bmx[a]);
+        }
+        const uint32_t k = lane < 6u ? lane : 0u, ka = k >> 1;
+        const bool upper = (k & 1u) != 0u;
+        const float geo_b = ka == 0 ? (upper ? bmx[0] : bmn[0]) : ka == 1 ? (upper ? bmx[1] : bmn[1]) : (upper ? bmx[2] : bmn[2]);
+        p_cam = sgn * (m_axis == 0 ? bla[0] : m_axis == 1 ? bla[1] : bla[2]);
+        // u = bla + (p - p_cam) * B = (bla - p_cam * B) + p * B: the first term rounds by an ulp of the camera's distance in
+        // texels (2.4e-4 at 4096), inside the slack
+        geo_c = __builtin_fmaf(-p_cam, geo_b, ka == 0 ? bla[0] : ka == 1 ? bla[1] : bla[2]) + (upper ? box_slack : -box_slack);
+        const bool geo_far = (geo_b >= 0.0f) == upper; // which of the two planes gives this bound
+        geo_bn = geo_far ? 0.0f : geo_b;
+        geo_bf = geo_far ? geo_b : 0.0f;
+        // (the clamps of chunk_box below: a box outside the volume (slab) degenerates)
+        geo_cl = upper ? -0x1p28f : (ka == 0 ? g.u_lo[0] : ka == 1 ? g.u_lo[1] : g.u_lo[2]) - 0.5f;
+        geo_ch = upper ? (ka == 0 ? g.u_hi[0] : ka == 1 ? g.u_hi[1] : g.u_hi[2]) : 0x1p28f;
+    }
     int steps_left = VRM_MAX_STEP_AMOUNT; // wgsl:139: at most 5000 iterations per ray
     // Empty space in long strides.  After an empty chunk the next one is tried 2^lvl times as deep and tested against level
     // lvl of the occupancy pyramid (cells 2^lvl times as wide: as many look-ups as a plain chunk); a deeper chunk that is not
@@ -685,12 +748,34 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             }
             return __builtin_amdgcn_ballot_w64(occ) == 0ull;
         };
+        // the same box from the tile's geometry (see geo_b above): every sample of a chunk of depth k lies between the planes
+        auto geo_box = [&](int k, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
+            const float far = __builtin_fmaf((float)k + 0.5f, smax, rear);
+            const int iv = floor_to_int(__builtin_amdgcn_fmed3f(__builtin_fmaf(rear, geo_bn, __builtin_fmaf(far, geo_bf, geo_c)), geo_cl, geo_ch));
+            bool inter = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int li = __builtin_amdgcn_readlane(iv, 2 * a), hh = __builtin_amdgcn_readlane(iv, 2 * a + 1) + 1;
+                inter = inter && li >= in_lo[a] && hh <= in_hi[a];
+                lo[a] = li;
+                hi[a] = hh;
+            }
+            return inter;
+        };
+        // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
+        auto lane_steps = [&](int k) __attribute__((always_inline)) -> int {
+            const float ahead = aligned ? (rear + ((float)k + 0.5f) * smax - prog) * inv_du_m : (float)k;
+            return active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)k), steps_left) : 0;
+        };
+        // (a camera inside the volume marches from t_min < 0, behind itself, where (p - p_cam) * B changes its sense)
+        const bool use_geo = GEO && __builtin_amdgcn_ballot_w64(!(rear >= p_cam)) == 0ull;
         bool empty = false;
         for (;;) {
-            // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
-            const float ahead = aligned ? (rear + ((float)kk + 0.5f) * smax - prog) * inv_du_m : (float)kk;
-            n_lane = active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)kk), steps_left) : 0;
-            interior = chunk_box(n_lane, ilo, ihi); // every step of every lane stays inside the volume (slab) with margin
+            if (use_geo) interior = geo_box(kk, ilo, ihi);
+            else {
+                n_lane = lane_steps(kk);
+                interior = chunk_box(n_lane, ilo, ihi); // every step of every lane stays inside the volume (slab) with margin
+            }
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
             // rows start on a 4-unit boundary: the staging loads are whole 16-byte quads of the bricked volume
             x0u = PACKED ? ilo[0] >> 2 : ilo[0];
@@ -706,6 +791,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
             if (DIAG) ++st_retry;
         }
+        if (use_geo) n_lane = lane_steps(kk);
         if (none) empty = true;
         else {
             if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
@@ -962,7 +1048,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                 w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
                                 w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
                                 float a255 = 1.0f;
-                                done = shade_packed<USE_TF, ERT>(w, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                done = shade_packed<USE_TF, ERT>(w, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             } else {
                                 uint32_t c[8];
@@ -971,7 +1057,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                 c[4] = ld(a2); c[5] = ld(a2 + 4);
                                 c[6] = ld(a3); c[7] = ld(a3 + 4);
                                 float a255 = 1.0f;
-                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc, DIAG ? &a255 : nullptr);
+                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             }
                         }
@@ -1003,7 +1089,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
                         fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, P, acc);
+                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc);
                     }
                     // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
                     dt += VRM_STEP_SIZE;
