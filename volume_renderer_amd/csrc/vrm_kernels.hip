@@ -582,13 +582,19 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // which chunk does not change any lane's own dt sequence: the image is bit-identical.
     // margin of the "interior chunk" test below: rounding of the one-FMA texel coordinate against the exact in-box test
     // (as integer bounds on the chunk's box, rounded outwards to whole texels)
-    int in_lo[3], in_hi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    // Kept in ONE vector register (the kernel is short of SGPRs): lane 2a holds in_lo[a], lane 2a+1 holds -in_hi[a], so
+    // that "bound k stays inside" reads (b_k ^ -(k & 1)) >= in_lim in every lane (~b = -b - 1: the upper bounds b + 1 <= in_hi).
+    int in_lim;
+    {
+        const uint32_t ka = (lane < 6u ? lane : 0u) >> 1;
+        const float ro_a = ka == 0 ? ray.ro[0] : ka == 1 ? ray.ro[1] : ray.ro[2];
+        const float sc_a = ka == 0 ? g.tex_scale[0] : ka == 1 ? g.tex_scale[1] : g.tex_scale[2];
+        const float bi_a = ka == 0 ? g.tex_bias[0] : ka == 1 ? g.tex_bias[1] : g.tex_bias[2];
         // (the ray origin is the camera position: the same for every lane)
-        const float eps = 0.021f + 2e-6f * (fabsf(ray.ro[a] * g.tex_scale[a]) + fabsf(g.tex_bias[a]));
-        in_lo[a] = uni((int)ceilf(g.u_lo[a] + eps));
-        in_hi[a] = uni((int)floorf(g.u_hi[a] - eps));
+        const float eps = 0.021f + 2e-6f * (fabsf(ro_a * sc_a) + fabsf(bi_a));
+        const float lo_a = ka == 0 ? g.u_lo[0] : ka == 1 ? g.u_lo[1] : g.u_lo[2];
+        const float hi_a = ka == 0 ? g.u_hi[0] : ka == 1 ? g.u_hi[1] : g.u_hi[2];
+        in_lim = (lane & 1u) ? -(int)floorf(hi_a - eps) : (int)ceilf(lo_a + eps);
     }
     int m_axis = 0;
     float sgn = 1.0f, smax = 0.0f;
@@ -706,7 +712,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                 const int li = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mn[a] - box_slack, g.u_lo[a] - 0.5f, 0x1p28f)), 63);
                 const int hh = __builtin_amdgcn_readlane(floor_to_int(__builtin_amdgcn_fmed3f(mx[a] + box_slack, -0x1p28f, g.u_hi[a])), 63) + 1;
                 // interior: min - 0.01 >= li >= in_lo >= u_lo + eps and max + 0.01 < hh <= in_hi <= u_hi - eps
-                inter = inter && li >= in_lo[a] && hh <= in_hi[a];
+                inter = inter && li >= __builtin_amdgcn_readlane(in_lim, 2 * a) && hh <= -__builtin_amdgcn_readlane(in_lim, 2 * a + 1);
                 lo[a] = li;
                 hi[a] = hh;
             }
@@ -752,15 +758,14 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         auto geo_box = [&](int k, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
             const float far = __builtin_fmaf((float)k + 0.5f, smax, rear);
             const int iv = floor_to_int(__builtin_amdgcn_fmed3f(__builtin_fmaf(rear, geo_bn, __builtin_fmaf(far, geo_bf, geo_c)), geo_cl, geo_ch));
-            bool inter = true;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const int li = __builtin_amdgcn_readlane(iv, 2 * a), hh = __builtin_amdgcn_readlane(iv, 2 * a + 1) + 1;
-                inter = inter && li >= in_lo[a] && hh <= in_hi[a];
-                lo[a] = li;
-                hi[a] = hh;
+                lo[a] = __builtin_amdgcn_readlane(iv, 2 * a);
+                hi[a] = __builtin_amdgcn_readlane(iv, 2 * a + 1) + 1;
             }
-            return inter;
+            // interior, all six bounds at once (see in_lim)
+            const int flip = -(int)(lane & 1u);
+            return (__builtin_amdgcn_ballot_w64((iv ^ flip) >= in_lim) & 0x3full) == 0x3full;
         };
         // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
         auto lane_steps = [&](int k) __attribute__((always_inline)) -> int {
@@ -768,7 +773,11 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             return active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)k), steps_left) : 0;
         };
         // (a camera inside the volume marches from t_min < 0, behind itself, where (p - p_cam) * B changes its sense)
-        const bool use_geo = GEO && __builtin_amdgcn_ballot_w64(!(rear >= p_cam)) == 0ull;
+        // (Not for a slab-partitioned volume either: its waves are active in part for much of their way -- rays enter and
+        // leave the slab at different planes -- and the hull of the lanes that still step is the tighter box there: 2.27
+        // against 2.39 ms/view for the C5 rank of profiles/r2.  Tested here, where g.slab is at hand anyway: a test at the
+        // tile's set-up costs the C3 instance ten more spilled SGPRs and 3 % of its time.)
+        const bool use_geo = GEO && !g.slab && __builtin_amdgcn_ballot_w64(!(rear >= p_cam)) == 0ull;
         bool empty = false;
         for (;;) {
             if (use_geo) interior = geo_box(kk, ilo, ihi);
