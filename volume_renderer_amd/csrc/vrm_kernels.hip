@@ -1152,7 +1152,6 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     }
     const uint32_t per_view = P.sblocks_x * P.sblocks_y * 8u; // tile slots of one view in one XCD's list
     const uint32_t total = per_view * P.n_views;
-    uint32_t xcd = blockIdx.x & 7u;
     // (Measured and dropped: claims of several tiles at once, +5 % for two and +40 % for eight -- what the L2 likes is
     // neighbouring tiles marched at the same time by neighbouring waves, not one after the other by one wave; a claim
     // issued one tile ahead to hide its latency, +5 % for the same reason, and 0 % when issued only in a tile's last chunks; counters kept in the XCD's own L2 without
@@ -1162,18 +1161,19 @@ __global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <=
     // are worth 1 % on C3 and 4 % on the packed march (more counters, or counters interleaved tile by tile instead of
     // super-block by super-block, lose it again: the waves on one counter should be enough to march a super-block's tiles
     // at about the same time).
-    uint32_t sub = (blockIdx.x >> 3) % VRM_QUEUE_SUBS;
-    for (uint32_t tried = 0; tried < 8u * VRM_QUEUE_SUBS;) {
+    // The wave's place in the queues is ONE number that lives through the tiles (SGPRs are short): the counter it claims
+    // from, xcd * SUBS + sub, in the low byte and the counters it has found exhausted above it.
+    constexpr uint32_t NCTR = 8u * VRM_QUEUE_SUBS;
+    static_assert((NCTR & (NCTR - 1u)) == 0u && NCTR <= 256u, "counter index wraps with a mask and fits a byte");
+    uint32_t place = (blockIdx.x & 7u) * VRM_QUEUE_SUBS + (blockIdx.x >> 3) % VRM_QUEUE_SUBS;
+    while ((place >> 8) < NCTR) {
+        const uint32_t ctr = place & 0xffu, xcd = ctr / VRM_QUEUE_SUBS, sub = ctr % VRM_QUEUE_SUBS;
         uint32_t c = 0;
-        if (threadIdx.x == 0) c = atomicAdd(&P.queue[(xcd * VRM_QUEUE_SUBS + sub) * 32u], 1u); // (counters 128 bytes apart)
+        if (threadIdx.x == 0) c = atomicAdd(&P.queue[ctr * 32u], 1u); // (counters 128 bytes apart)
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         const uint32_t q = (((c >> 6) * VRM_QUEUE_SUBS + sub) << 6) + (c & 63u);
         if (q >= total) { // this counter's super-blocks are done: the next counter, after the last one the next XCD's list
-            ++tried;
-            if (++sub == VRM_QUEUE_SUBS) {
-                sub = 0;
-                xcd = (xcd + 1u) & 7u;
-            }
+            place = ((place & ~0xffu) + 0x100u) | ((ctr + 1u) & (NCTR - 1u));
             continue;
         }
         const uint32_t view = q / per_view;
