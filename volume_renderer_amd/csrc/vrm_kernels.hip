@@ -18,6 +18,9 @@
 #ifndef VRM_CAP_DEFAULT
 #define VRM_CAP_DEFAULT 2560 /* LDS words per wave of the default march (A/B builds override it) */
 #endif
+#ifndef VRM_CAP_PACKED
+#define VRM_CAP_PACKED VRM_CAP_DEFAULT /* LDS words per wave of the packed 1-channel march */
+#endif
 #ifndef VRM_SKIP_MAX_LEVEL
 #define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
 #endif
@@ -128,9 +131,10 @@ struct Accum {
 
 // The transfer function's three colours, held in VGPRs on purpose: the march kernel is short of SGPRs, and nine uniform
 // floats that every sample reads were what the register allocator spilled to VGPR lanes and read back per sample
-// (v_readlane + v_mov in the step loop).  As vector registers they feed v_cndmask directly.
+// (v_readlane + v_mov in the step loop).  Held in the select-free form of tf_blend() below: colour A and the doubled
+// differences 2(B - A), 2(C - B).
 struct TfRegs {
-    float a[3], b[3], c[3];
+    float a[3], d1[3], d2[3];
 };
 template <bool USE_TF>
 __device__ __forceinline__ TfRegs tf_regs(const VrmMarchParams &P)
@@ -140,12 +144,28 @@ __device__ __forceinline__ TfRegs tf_regs(const VrmMarchParams &P)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             t.a[i] = P.col_a[i];
-            t.b[i] = P.col_b[i];
-            t.c[i] = P.col_c[i];
-            asm volatile("" : "+v"(t.a[i]), "+v"(t.b[i]), "+v"(t.c[i]));
+            t.d1[i] = (P.col_b[i] - P.col_a[i]) * 2.0f;
+            t.d2[i] = (P.col_c[i] - P.col_b[i]) * 2.0f;
+            asm volatile("" : "+v"(t.a[i]), "+v"(t.d1[i]), "+v"(t.d2[i]));
         }
     }
     return t;
+}
+
+// The transfer function (wgsl:145-147: A -> B for a in [0, 0.5], B -> C above, piecewise linear) times the sample's weight,
+// added to the colour.  Written without selects: with h = max(a - 0.5, 0) and l = a - h = min(a, 0.5) (both exact)
+// colour = A + l * 2(B - A) + h * 2(C - B).  On gfx950 a v_cndmask_b32 that takes its mask from VCC costs 20+ cycles
+// unless it directly follows the compare (tools/probes/valu_probe3.hip: one compare + seven selects, the form the compiler
+// gives `hi ? x : y` on nine colours, averages 16 cycles per instruction against 2.5-4.3 for everything else); this form
+// is one v_max and eight full-rate operations.  a22: the filtered alpha in units of 2^-22 texel levels.
+__device__ __forceinline__ void tf_blend(const float a22, const float w, const TfRegs &P, Accum &acc)
+{
+    const float a = a22 * (T22 * (1.0f / 255.0f));
+    const float h = fmaxf(a - 0.5f, 0.0f);
+    const float l = a - h;
+    acc.cr = __builtin_fmaf(w, __builtin_fmaf(h, P.d2[0], __builtin_fmaf(l, P.d1[0], P.a[0])), acc.cr);
+    acc.cg = __builtin_fmaf(w, __builtin_fmaf(h, P.d2[1], __builtin_fmaf(l, P.d1[1], P.a[1])), acc.cg);
+    acc.cb = __builtin_fmaf(w, __builtin_fmaf(h, P.d2[2], __builtin_fmaf(l, P.d1[2], P.a[2])), acc.cb);
 }
 
 // Trilinear filter of the 8 corner texels (c[z][y][x] as RGBA8 words) + transfer function (wgsl:145-147)
@@ -179,16 +199,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     const float om = 1.0f - acc.alpha;
     const float w = om * alpha_src;
     if (USE_TF) {
-        // piecewise-linear in a with the breakpoint at 0.5: A->B below, B->C above
-        const float a = a22 * (T22 * (1.0f / 255.0f));
-        const bool hi = a >= 0.5f;
-        const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
-        const float s0 = hi ? P.b[0] : P.a[0], e0 = hi ? P.c[0] : P.b[0];
-        const float s1 = hi ? P.b[1] : P.a[1], e1 = hi ? P.c[1] : P.b[1];
-        const float s2 = hi ? P.b[2] : P.a[2], e2 = hi ? P.c[2] : P.b[2];
-        acc.cr = __builtin_fmaf(w, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
-        acc.cg = __builtin_fmaf(w, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
-        acc.cb = __builtin_fmaf(w, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
+        tf_blend(a22, w, P, acc);
     } else if (ALPHA_ONLY) {
         acc.cr = __builtin_fmaf(w, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
     } else if (__builtin_amdgcn_ballot_w64(a22 != 0.0f) != 0ull) {
@@ -204,19 +215,22 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     return ERT ? acc.alpha >= 1.0f : false;
 }
 
-// The 1-channel march from the packed alpha copy (VrmGridDev::abricks): w[i] holds texel x of row i in byte 0 and
-// texel x+1 in byte 1 (rows: y0z0, y1z0, y0z1, y1z1).  Same arithmetic on the same values as shade<true, USE_TF>.
+// The 1-channel march from the packed alpha copy (VrmGridDev::abricks), whose LDS tile is addressed in BYTES: t[2r] and
+// t[2r + 1] are the alpha bytes of texels x and x + 1 of row r (rows: y0z0, y1z0, y0z1, y1z1), each read by its own
+// ds_read_u8.  A zero-extended byte IS the f32 denormal b * 2^-149, so the filter is plain full-rate f32 arithmetic with
+// no conversion at all: the difference of two denormals is exact, a multiply by 2^127 and an FMA with the 2^127-scaled
+// weight bring them into the normal range.  Same values, same operations as shade<true, USE_TF> on the RGBA words (and as
+// the alignbyte + SDWA form this replaces: 8 ds_read_u8 cost the LDS what 4 ds_read2_b32 did, tools/probes/valu_probe2.hip).
 template <bool USE_TF, bool ERT>
-__device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, float wy, float wz, float kexp22, const TfRegs &P,
-                                             Accum &acc, float *a_out = nullptr)
+__device__ __forceinline__ bool shade_bytes(const uint32_t t[8], float wx, float wy, float wz, float kexp22, const TfRegs &P,
+                                            Accum &acc, float *a_out = nullptr)
 {
     const float wxs = wx * 0x1p127f;
-    auto xlerp = [&](uint32_t t) -> float {
-        float d; // (byte 1) - (byte 0) as the exact denormal difference
-        asm("v_sub_f32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "=v"(d) : "v"(t));
-        return __builtin_fmaf(d, wxs, byte_scaled<0>(t));
+    auto xlerp = [&](uint32_t t0, uint32_t t1) -> float {
+        const float b0 = __builtin_bit_cast(float, t0), b1 = __builtin_bit_cast(float, t1);
+        return __builtin_fmaf(b1 - b0, wxs, b0 * 0x1p127f);
     };
-    const float c00 = xlerp(w[0]), c10 = xlerp(w[1]), c01 = xlerp(w[2]), c11 = xlerp(w[3]);
+    const float c00 = xlerp(t[0], t[1]), c10 = xlerp(t[2], t[3]), c01 = xlerp(t[4], t[5]), c11 = xlerp(t[6], t[7]);
     const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
     const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
     const float a22 = __builtin_fmaf(wz, c1 - c0, c0);
@@ -224,19 +238,8 @@ __device__ __forceinline__ bool shade_packed(const uint32_t w[4], float wx, floa
     const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a22 * kexp22);
     const float om = 1.0f - acc.alpha;
     const float wgt = om * alpha_src;
-    if (USE_TF) {
-        const float a = a22 * (T22 * (1.0f / 255.0f));
-        const bool hi = a >= 0.5f;
-        const float t = hi ? (a - 0.5f) * 2.0f : a * 2.0f;
-        const float s0 = hi ? P.b[0] : P.a[0], e0 = hi ? P.c[0] : P.b[0];
-        const float s1 = hi ? P.b[1] : P.a[1], e1 = hi ? P.c[1] : P.b[1];
-        const float s2 = hi ? P.b[2] : P.a[2], e2 = hi ? P.c[2] : P.b[2];
-        acc.cr = __builtin_fmaf(wgt, __builtin_fmaf(t, e0 - s0, s0), acc.cr);
-        acc.cg = __builtin_fmaf(wgt, __builtin_fmaf(t, e1 - s1, s1), acc.cg);
-        acc.cb = __builtin_fmaf(wgt, __builtin_fmaf(t, e2 - s2, s2), acc.cb);
-    } else {
-        acc.cr = __builtin_fmaf(wgt, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
-    }
+    if (USE_TF) tf_blend(a22, wgt, P, acc);
+    else acc.cr = __builtin_fmaf(wgt, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
     acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
     return ERT ? acc.alpha >= 1.0f : false;
 }
@@ -1010,10 +1013,10 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             // chunk's box starts: any chunking, data-dependent ones included, gives bit-identical accumulators.
             const float o1 = (float)ilo[1], o2 = (float)ilo[2];
             const float fpx4 = (float)(4 * pitch), fsl4 = (float)(4 * slice);
-            const float x04 = -4.0f * (float)x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
+            const float x04 = -4.0f * (float)x0u; // first staged column in row units (texels; words of 4 texels when PACKED), in bytes
             const int pitch4 = 4 * pitch, slice4 = 4 * slice;
-            // byte address of the last corner cell (PACKED: of the last word a sample's texel x can lie in)
-            const float amax4 = (float)(4 * ((nz - 2) * slice + (ny - 2) * pitch + (nx - (PACKED ? 1 : 2))));
+            // byte address of the last corner cell (PACKED: rows of 4 * nx texel bytes, the cell's x + 1 is the last one)
+            const float amax4 = (float)(4 * ((nz - 2) * slice + (ny - 2) * pitch) + (PACKED ? 4 * nx - 2 : 4 * (nx - 2)));
             const char *tile_b = reinterpret_cast<const char *>(tile);
             auto ld = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(tile_b + byte_off); };
             auto steps = [&](auto interior_c) {
@@ -1044,20 +1047,23 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                             // the box holds floor(u) and floor(u)+1 of every in-box sample by construction (0.01 texel
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
-                            // (PACKED: the column is the word floor(x / 4); byte x & 3 of it and the byte after)
-                            const float fc = PACKED ? floorf(f0 * 0.25f) : f0;
-                            const float af = __builtin_fmaf(f2 - o2, fsl4, __builtin_fmaf(f1 - o1, fpx4, __builtin_fmaf(fc, 4.0f, x04))); // exact: small integers
+                            // (PACKED: the tile's rows are byte-linear in x -- byte x - 4 * x0u of the row is texel x)
+                            const float af = __builtin_fmaf(f2 - o2, fsl4, __builtin_fmaf(f1 - o1, fpx4, PACKED ? f0 + x04 : __builtin_fmaf(f0, 4.0f, x04))); // exact: small integers
                             const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax4);
                             const int a1 = a0 + pitch4, a2 = a0 + slice4, a3 = a2 + pitch4;
                             if constexpr (PACKED) {
-                                const uint32_t sh = (uint32_t)(int)f0 & 3u;
-                                uint32_t w[4];
-                                w[0] = __builtin_amdgcn_alignbyte(ld(a0 + 4), ld(a0), sh);
-                                w[1] = __builtin_amdgcn_alignbyte(ld(a1 + 4), ld(a1), sh);
-                                w[2] = __builtin_amdgcn_alignbyte(ld(a2 + 4), ld(a2), sh);
-                                w[3] = __builtin_amdgcn_alignbyte(ld(a3 + 4), ld(a3), sh);
+                                // (written out: the compiler merges the byte pair of a row into one ds_read_u16, and a halfword read
+                                // at an odd address, which every other sample's is, takes six times as long -- valu_probe2)
+                                uint32_t t[8];
+                                const uint32_t tb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)tile_b;
+                                asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %9\n\tds_read_u8 %3, %9 offset:1\n\t"
+                                             "ds_read_u8 %4, %10\n\tds_read_u8 %5, %10 offset:1\n\tds_read_u8 %6, %11\n\tds_read_u8 %7, %11 offset:1\n\t"
+                                             "s_waitcnt lgkmcnt(0)"
+                                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                                             : "v"(tb + (uint32_t)a0), "v"(tb + (uint32_t)a1), "v"(tb + (uint32_t)a2), "v"(tb + (uint32_t)a3)
+                                             : "memory");
                                 float a255 = 1.0f;
-                                done = shade_packed<USE_TF, ERT>(w, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
+                                done = shade_bytes<USE_TF, ERT>(t, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             } else {
                                 uint32_t c[8];
@@ -1142,7 +1148,8 @@ template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACK
 #ifdef VRM_AB_LDS_PAD
 __global__ void __launch_bounds__(64, 2) march_lds_kernel
 #else
-__global__ void __launch_bounds__(64, (CAP < 2560 ? 5 : CAP <= 2560 ? 4 : CAP <= 3072 ? 3 : 2)) march_lds_kernel
+// (waves per SIMD = what 160 KB of LDS per CU hold at CAP words per one-wave workgroup, which is also the register budget)
+__global__ void __launch_bounds__(64, (163840 / (CAP * 4) / 4 > 8 ? 8 : 163840 / (CAP * 4) / 4 < 1 ? 1 : 163840 / (CAP * 4) / 4)) march_lds_kernel
 #endif
 (const VrmMarchParams P)
 {
@@ -1523,6 +1530,12 @@ __global__ void __launch_bounds__(256) detect_nonscalar_kernel(const uint32_t *_
     }
 }
 
+#ifdef VRM_ISA_ONE
+// ISA inspection build (tools/isa_blocks.py --one): a single instantiation of the march kernel, no launchers -- compiles in
+// seconds instead of minutes.  VRM_ISA_ONE = the template arguments.
+template __global__ void march_lds_kernel<VRM_ISA_ONE>(const VrmMarchParams P);
+} // namespace
+#else
 inline uint32_t stream_blocks(size_t n)
 {
     size_t b = (n + 255) / 256;
@@ -1587,7 +1600,7 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
             bool done = false;
             if constexpr (A) {
                 if (p.grid.abricks != nullptr && p.packed_alpha != 0) {
-                    VRM_LDS(VRM_CAP_DEFAULT, 15.0f, true);
+                    VRM_LDS(VRM_CAP_PACKED, 15.0f, true);
                     done = true;
                 }
             }
@@ -1744,3 +1757,4 @@ hipError_t vrm_launch_composite(const float *partials, uint32_t n_slabs, const V
                        reinterpret_cast<float4 *>(out_f32));
     return hipGetLastError();
 }
+#endif // VRM_ISA_ONE
