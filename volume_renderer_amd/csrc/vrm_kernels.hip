@@ -900,12 +900,43 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                 const int eyl = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)qpr)), q = (int)lane - eyl * qpr;
                 const uint32_t bx = ((uint32_t)x0u >> 2) + (uint32_t)q;
                 const size_t zslab = (size_t)src_nbx * g.nby * 128u;   // bytes per brick layer (2 slices)
+                // The usual box lies inside the volume in z as well: no clamp per slice, and the slices of one brick layer are
+                // 64 bytes apart.  Written out (one s_mov m0 + the load per slice, one 64-bit scalar add per layer, the lane mask set
+                // once per row block): the compiler's form of the general loop below spends 20 scalar instructions per load on
+                // the clamp and a 64-bit multiply-add, and the CU's one scalar unit issues 0.95 instructions per cycle for all
+                // its waves (tools/probes/salu_probe.hip) -- it was as busy as the vector units (C4: 0.70 per CU-cycle).
+                const bool z_plain = ilo[2] >= 0 && ilo[2] + nz - 1 <= mxz && zslab < (1ull << 31);
                 for (int eb = 0; eb * rpw < ny; ++eb) {
                     const int ey = eb * rpw + eyl;
                     const bool lane_on = eyl < rpw && ey < ny;
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                     const uint32_t voff = (((gy >> 2) * src_nbx + bx) * 8u + (gy & 3u)) * 16u;
                     uint32_t *drow = &tile[eb * rpw * pitch];
+                    if (z_plain) {
+                        if (lane_on) {
+                            auto dma = [](uint32_t lds_byte, uint32_t off, const char *base) __attribute__((always_inline)) {
+                                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(off), "s"(base) : "memory");
+                            };
+                            uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)drow;
+                            const uint32_t lds_step = (uint32_t)slice * 4u, voff1 = voff + 64u;
+                            const char *lay = reinterpret_cast<const char *>(src) + (size_t)((uint32_t)ilo[2] >> 1) * zslab;
+                            int ez = 0;
+                            if (ilo[2] & 1) {
+                                dma(lds, voff1, lay);
+                                lay += zslab;
+                                lds += lds_step;
+                                ez = 1;
+                            }
+                            for (; ez + 1 < nz; ez += 2) {
+                                dma(lds, voff, lay);
+                                dma(lds + lds_step, voff1, lay);
+                                lay += zslab;
+                                lds += 2u * lds_step;
+                            }
+                            if (ez < nz) dma(lds, voff, lay);
+                        }
+                        continue;
+                    }
                     for (int ez = 0; ez < nz; ++ez) {
                         const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz); // uniform
                         const char *zbase = reinterpret_cast<const char *>(src) + (size_t)(gz >> 1) * zslab + (gz & 1u) * 64u;
@@ -1021,8 +1052,13 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             auto ld = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(tile_b + byte_off); };
             auto steps = [&](auto interior_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
-                for (int j = 0; j < kk; ++j) {
-                    if (j < n_lane && active) {
+                // (The lane's state inside the loop is ONE vector register: the step it stops at, -1 once the ray has ended.  As
+                // `j < n_lane && active` with the mask `active` updated per step the loop carried 20 scalar instructions per
+                // sample -- see the staging loop above for what they cost.)
+                int lim = active ? n_lane : 0;
+                const int kku = uni(kk); // (wave-uniform by construction; said so, the loop control is scalar)
+                for (int j = 0; j < kku; ++j) {
+                    if (j < lim) {
                         if (DIAG) ++iters;
                         bool inside = true;
                         if constexpr (!INTERIOR) {
@@ -1078,9 +1114,10 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                         }
                         // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
                         dt += VRM_STEP_SIZE;
-                        active = !(done || dt >= ray.t_max);
+                        lim = (done || dt >= ray.t_max) ? -1 : lim;
                     }
                 }
+                active = active && lim >= 0;
             };
             if (interior) steps(std::true_type{});
             else steps(std::false_type{});
