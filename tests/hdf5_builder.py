@@ -196,8 +196,8 @@ def old_style(color, dims_extra=None):
     sb = img.alloc(8 + 8 + 4 + 4 + 4 * 8 + 40)      # signature + versions/sizes + K + flags + 4 addresses + root entry
     data_addr = img.append(color.tobytes())
     objs = {"c": object_header_v1(img, dimension_scale_messages(color.shape[0], False)),
-            "z": object_header_v1(img, dimension_scale_messages(Z, False)),
-            "y": object_header_v1(img, dimension_scale_messages(Y, False)),
+            "z": object_header_v1(img, dimension_scale_messages((dims_extra or {}).get("z", Z), False)),
+            "y": object_header_v1(img, dimension_scale_messages((dims_extra or {}).get("y", Y), False)),
             "x": object_header_v1(img, dimension_scale_messages((dims_extra or {}).get("x", X), False)),
             "color": object_header_v1(img, [(0x01, msg_dataspace_v1(color.shape)), (0x03, msg_datatype_f32(False)),
                                             (0x05, struct.pack("<BBBB", 2, 2, 2, 0)),          # fill value message (ignored)

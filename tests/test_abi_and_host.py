@@ -152,3 +152,24 @@ def test_rust_patch_keeps_reference_signatures():
         state = open(os.path.join(ref, "state.rs")).read()
         touched = set(re.findall(r"ray_marcher\.voxel_grid\.(\w+)", state)) | set(re.findall(r"ray_marcher\.(\w+)\(", state))
         assert touched <= {"attenuation", "transfer_function_colors", "update_voxel_grid_buffer", "update_transfer_function_buffer", "draw"}, touched
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r2: the dlopen-miss path called dlerror() twice (the second call returns NULL -> std::string(nullptr)).  Forced
+    here with VRM_RCCL_LIB pointing at nothing, in a child process (the binding is made once per process)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "from volume_renderer_amd import _ffi\n"
+        "L = ctypes.CDLL(_ffi.LIB_PATH)\n"
+        "L.vrm_last_error.restype = ctypes.c_char_p\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = L.vrm_comm_unique_id(buf)\n"
+        "print(rc, L.vrm_last_error().decode())\n"
+    )
+    env = dict(os.environ, VRM_RCCL_LIB="/nonexistent/librccl.so.1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == -2 and "RCCL not found" in msg and "nonexistent" in msg

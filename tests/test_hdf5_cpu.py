@@ -100,3 +100,46 @@ def test_lookup3_known_answers():
     assert hb.lookup3(b"", 0xDEADBEEF) == 0xBD5B7DDE
     assert hb.lookup3(b"Four score and seven years ago", 0) == 0x17770551
     assert hb.lookup3(b"Four score and seven years ago", 1) == 0xCD628161
+
+
+def _raw_read(path, capacity_floats):
+    """vrm_netcdf_read_color with a caller-sized buffer, as a C / Rust caller would call it"""
+    import ctypes
+    from volume_renderer_amd import _ffi
+    L = _ffi.lib()
+    x, y, z = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    buf = (ctypes.c_float * max(capacity_floats, 1))()
+    return L.vrm_netcdf_read_color(os.fsencode(path), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z), buf, capacity_floats)
+
+
+def test_dimensions_whose_product_wraps_are_refused(tmp_path):
+    """4*z*y*x with z = 2^22, y = x = 2^21 is 0 modulo 2^64 -- the capacity check passed and a chunked file then
+    wrote through the caller's (empty) buffer.  The element count is now formed with overflow checks, in the size query too."""
+    import struct
+    d = _data((7, 10, 13), 2)
+    shape, huge = struct.pack("<QQQQ", 4, 7, 10, 13), struct.pack("<QQQQ", 4, 1 << 22, 1 << 21, 1 << 21)
+    blob, _ = hb.new_style(d, chunk=(2, 3, 4, 5), skip_chunk=None, unfiltered_chunk=None)
+    assert blob.count(shape) >= 1                           # the dataspace of `color` (current and maximum dimensions)
+    p = _write(tmp_path, "wrap.nc", blob.replace(shape, huge))
+    assert _raw_read(p, 16) == -4                           # VRM_ERR_IO, and nothing written (here the dimension scales disagree first)
+    # the same with dimension scales that agree, so that the element count itself is what refuses
+    blob = hb.old_style(d, dims_extra={"x": 1 << 21, "y": 1 << 21, "z": 1 << 22})
+    assert blob.count(shape) == 1
+    p = _write(tmp_path, "wrap2.nc", blob.replace(shape, huge))
+    assert _raw_read(p, 16) == -4
+    with pytest.raises(VrmError) as e:                      # the size query refuses as well
+        netcdf.read_color(p)
+    assert "does not fit" in str(e.value)
+
+
+def test_chunk_larger_than_the_dataset_is_refused(tmp_path):
+    """a tiny file must not make the reader stage a chunk of gigabytes: chunk dimensions are bounded by the dataset's"""
+    import struct
+    d = _data((4, 4, 6), 3)
+    blob, _ = hb.new_style(d, chunk=(4, 2, 2, 3), skip_chunk=None, unfiltered_chunk=None, filters=())
+    chunk = struct.pack("<IIII", 4, 2, 2, 3)
+    assert blob.count(chunk) == 1                           # the version-3 layout message
+    evil = blob.replace(chunk, struct.pack("<IIII", 4, 1 << 12, 1 << 12, 3))
+    with pytest.raises(VrmError) as e:
+        netcdf.read_color(_write(tmp_path, "bigchunk.nc", evil))
+    assert "chunk dimension" in str(e.value)

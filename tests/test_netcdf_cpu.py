@@ -134,3 +134,17 @@ def test_errors(tmp_path):
         netcdf.read_color(trunc)
     with pytest.raises(ValueError):
         netcdf.write_color(good, np.zeros((3, 2, 2, 2), np.float32))
+
+
+def test_cdf5_dimensions_whose_product_wraps_are_refused(tmp_path):
+    """three dimensions below 2^32 each can still wrap the 64-bit element count (2^22 * 2^21 * 2^21 * 4 = 2^66)"""
+    class Shape:                                             # just enough of an array for _cdf5's header
+        shape = (4, 1 << 22, 1 << 21, 1 << 21)
+        size = 0
+        def astype(self, _):
+            return np.zeros(4, ">f4")
+    p = os.path.join(tmp_path, "wrap5.nc")
+    _cdf5(p, Shape())
+    with pytest.raises(VrmError) as e:
+        netcdf.read_color(p)
+    assert e.value.status == -4

@@ -899,12 +899,23 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl q;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (q.lib) break;
+        // VRM_RCCL_LIB names the library to bind instead of the usual candidates (a site's own build; the CPU test of the
+        // "no RCCL on this machine" path points it at nothing)
+        const char *forced = getenv("VRM_RCCL_LIB");
+        std::string last;
+        if (forced && *forced) {
+            q.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!q.lib) { const char *e = dlerror(); last = e ? e : "dlopen failed"; } // (dlerror() clears the message it returns: one call)
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (q.lib) break;
+                const char *e = dlerror();
+                last = e ? e : "dlopen failed";
+            }
         }
         if (!q.lib) {
-            q.why = std::string("RCCL not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")";
+            q.why = "RCCL not found (" + last + ")";
             return q;
         }
         q.GetUniqueId = reinterpret_cast<decltype(q.GetUniqueId)>(dlsym(q.lib, "ncclGetUniqueId"));
@@ -931,14 +942,16 @@ int rccl_fail(const char *what, int code)
 extern "C" int vrm_comm_unique_id(vrm_comm_id *id)
 {
     REQUIRE(id != nullptr, "null id");
-    Rccl &r = rccl();
-    if (!r.lib) {
-        vrm_set_error("%s", r.why.c_str());
-        return VRM_ERR_NO_DEVICE;
-    }
-    static_assert(sizeof(vrm_comm_id) == 128, "ncclUniqueId is 128 bytes");
-    const int e = r.GetUniqueId(id);
-    return e == 0 ? VRM_OK : rccl_fail("ncclGetUniqueId", e);
+    return vrm_guard("vrm_comm_unique_id", VRM_ERR_NO_DEVICE, [&]() -> int { // (binding RCCL builds strings: nothing throws across the ABI)
+        Rccl &r = rccl();
+        if (!r.lib) {
+            vrm_set_error("%s", r.why.c_str());
+            return VRM_ERR_NO_DEVICE;
+        }
+        static_assert(sizeof(vrm_comm_id) == 128, "ncclUniqueId is 128 bytes");
+        const int e = r.GetUniqueId(id);
+        return e == 0 ? VRM_OK : rccl_fail("ncclGetUniqueId", e);
+    });
 }
 
 extern "C" int vrm_comm_init(vrm_ctx *ctx, const vrm_comm_id *id, int rank, int n_ranks)
@@ -948,18 +961,20 @@ extern "C" int vrm_comm_init(vrm_ctx *ctx, const vrm_comm_id *id, int rank, int 
     REQUIRE(id != nullptr, "null id");
     REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
     REQUIRE(ctx->comm == nullptr, "this context already has a communicator (vrm_comm_destroy first)");
-    Rccl &r = rccl();
-    if (!r.lib) {
-        vrm_set_error("%s", r.why.c_str());
-        return VRM_ERR_NO_DEVICE;
-    }
-    void *comm = nullptr;
-    const int e = r.CommInitRank(&comm, n_ranks, *id, rank); // collective: every rank of the job calls it
-    if (e != 0) return rccl_fail("ncclCommInitRank", e);
-    ctx->comm = comm;
-    ctx->comm_rank = rank;
-    ctx->comm_size = n_ranks;
-    return VRM_OK;
+    return vrm_guard("vrm_comm_init", VRM_ERR_NO_DEVICE, [&]() -> int {
+        Rccl &r = rccl();
+        if (!r.lib) {
+            vrm_set_error("%s", r.why.c_str());
+            return VRM_ERR_NO_DEVICE;
+        }
+        void *comm = nullptr;
+        const int e = r.CommInitRank(&comm, n_ranks, *id, rank); // collective: every rank of the job calls it
+        if (e != 0) return rccl_fail("ncclCommInitRank", e);
+        ctx->comm = comm;
+        ctx->comm_rank = rank;
+        ctx->comm_size = n_ranks;
+        return VRM_OK;
+    });
 }
 
 extern "C" int vrm_grid_broadcast(vrm_ctx *ctx, int root)

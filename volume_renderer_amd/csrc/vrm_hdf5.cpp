@@ -103,7 +103,8 @@ std::vector<Message> object_header(H5 &h, uint64_t addr)
     bool v2 = memcmp(sig, "OHDR", 4) == 0;
     bool track_order = false;
     if (v2) {
-        auto b = h.block(addr, 64);
+        if (addr >= h.file_size) h.fail("object header beyond the end of the file");
+        auto b = h.block(addr, (size_t)std::min<uint64_t>(64, h.file_size - addr)); // (a short header may end the file)
         Cur c(h, b.data(), b.size());
         c.skip(4);
         if (c.u(1) != 2) h.fail("object header version is not 2");
@@ -303,6 +304,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                     d.size = c.len();
                 } else if (cls == 2) {
                     const uint64_t fl = c.u(1), nd = c.u(1), enc = c.u(1);
+                    if (enc < 1 || enc > 8) h.fail("chunk dimension size encoded in %llu bytes", (unsigned long long)enc);
                     for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u((int)enc));
                     c.u((int)enc);
                     const uint64_t idx = c.u(1);
@@ -318,6 +320,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
             }
         } else if (m.type == 0x000B) { // filter pipeline
             const uint64_t ver = c.u(1), n = c.u(1);
+            if (n > 32) h.fail("filter pipeline of %llu filters (the format allows 32)", (unsigned long long)n);
             if (ver == 1) c.skip(6);
             else if (ver != 2) h.fail("filter pipeline version %llu", (unsigned long long)ver);
             for (uint64_t i = 0; i < n; ++i) {
@@ -343,7 +346,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
 void decode_chunk(H5 &h, const Dataset &d, uint64_t addr, uint64_t stored, uint32_t mask, size_t chunk_bytes, std::vector<uint8_t> &raw,
                   std::vector<uint8_t> &tmp)
 {
-    if (stored > ((uint64_t)1 << 31)) h.fail("chunk of %llu bytes is not plausible", (unsigned long long)stored);
+    if (stored > ((uint64_t)1 << 31) || stored > h.file_size) h.fail("chunk of %llu bytes is not plausible", (unsigned long long)stored);
     tmp.resize((size_t)stored);
     h.read(addr, tmp.data(), (size_t)stored);
     size_t cur = (size_t)stored;
@@ -377,7 +380,9 @@ void copy_chunk(const Dataset &d, const std::vector<uint64_t> &origin, const uin
     // 4-d chunk at `origin` (elements) into the row-major (c, z, y, x) array; edge chunks are stored whole, clipped here
     const uint64_t *D = d.dims.data(), *C = d.chunk.data();
     if (origin[0] >= D[0] || origin[1] >= D[1] || origin[2] >= D[2] || origin[3] >= D[3]) return;
-    const uint64_t n3 = (origin[3] + C[3] <= D[3]) ? C[3] : D[3] - origin[3];
+    // (origin < D on every axis and the loops below stop at D: the last element written is inside the (c, z, y, x) array,
+    // whose size vrm_hdf5_read_color has checked against the caller's buffer without wrap-around)
+    const uint64_t n3 = (C[3] <= D[3] - origin[3]) ? C[3] : D[3] - origin[3];
     for (uint64_t a = 0; a < C[0] && origin[0] + a < D[0]; ++a)
         for (uint64_t b = 0; b < C[1] && origin[1] + b < D[1]; ++b)
             for (uint64_t c = 0; c < C[2] && origin[2] + c < D[2]; ++c) {
@@ -396,6 +401,10 @@ void read_chunked(H5 &h, const Dataset &d, float *out)
         if (chunk_bytes > ((size_t)1 << 32) / (size_t)c) h.fail("chunk too large");
         chunk_bytes *= (size_t)c;
     }
+    // (a chunk larger than the dataset it tiles is not something a writer produces; refusing it keeps a 100-byte file from
+    // asking for gigabytes of staging memory)
+    for (size_t k = 0; k < 4; ++k)
+        if (d.chunk[k] > d.dims[k]) h.fail("chunk dimension %zu is %llu, the dataset's is %llu", k, (unsigned long long)d.chunk[k], (unsigned long long)d.dims[k]);
     std::vector<uint8_t> raw, tmp;
     if (d.layout == 3) {
         if (d.addr == UNDEF) return; // never written: fill value 0
@@ -521,8 +530,17 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
         *z = (uint32_t)d.dims[1];
         *y = (uint32_t)d.dims[2];
         *x = (uint32_t)d.dims[3];
+        {
+            uint64_t t = 0; // (a caller sizes its buffer as 4*x*y*z from this query: refuse dimensions whose product wraps)
+            if (__builtin_mul_overflow(d.dims[1], d.dims[2], &t) || __builtin_mul_overflow(t, d.dims[3], &t) || t > (uint64_t)SIZE_MAX / 16)
+                h.fail("color(4,%llu,%llu,%llu) does not fit the address space", (unsigned long long)d.dims[1], (unsigned long long)d.dims[2], (unsigned long long)d.dims[3]);
+        }
         if (!out) return VRM_OK;
-        const uint64_t n = 4ull * d.dims[1] * d.dims[2] * d.dims[3];
+        // 4 * z * y * x floats: each dimension is < 2^32, so the product of three can wrap 64 bits -- checked, not assumed
+        uint64_t n = 0;
+        if (__builtin_mul_overflow(d.dims[1], d.dims[2], &n) || __builtin_mul_overflow(n, d.dims[3], &n) || __builtin_mul_overflow(n, (uint64_t)4, &n) ||
+            n > (uint64_t)SIZE_MAX / 4)
+            h.fail("color(4,%llu,%llu,%llu) does not fit the address space", (unsigned long long)d.dims[1], (unsigned long long)d.dims[2], (unsigned long long)d.dims[3]);
         if (capacity_floats < n) {
             vrm_set_error("%s holds %llu floats, buffer holds %zu", path, (unsigned long long)n, capacity_floats);
             return VRM_ERR_INVALID;

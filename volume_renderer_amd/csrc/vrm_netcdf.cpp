@@ -172,6 +172,12 @@ struct Writer {
 
 } // namespace
 
+static bool mul3_overflows(uint64_t a, uint64_t b, uint64_t c)
+{
+    uint64_t t = 0;
+    return __builtin_mul_overflow(a, b, &t) || __builtin_mul_overflow(t, c, &t) || t > (uint64_t)SIZE_MAX / 16;
+}
+
 extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *color_czyx, size_t capacity_floats)
 {
     return vrm_guard("vrm_netcdf_read_color", VRM_ERR_IO, [&]() -> int {
@@ -195,7 +201,7 @@ extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y,
     *z = (uint32_t)h.z;
     struct stat st;
     REQUIRE_IO(fstat(fileno(fl.f), &st) == 0 && (uint64_t)st.st_size >= h.begin &&
-                   ((uint64_t)st.st_size - h.begin) / 16 >= h.x * h.y * h.z,   // (x, y, z < 2^32 each: the product of two fits 64 bits)
+                   !mul3_overflows(h.x, h.y, h.z) && ((uint64_t)st.st_size - h.begin) / 16 >= h.x * h.y * h.z,   // (x, y, z < 2^32 each: the product of THREE can wrap 64 bits)
                "%s: data of 'color' is truncated: the header promises color(4,%llu,%llu,%llu) but the file has only %lld bytes", path, (unsigned long long)h.z,
                (unsigned long long)h.y, (unsigned long long)h.x, (long long)st.st_size);
     if (!color_czyx) return VRM_OK; // size query
