@@ -92,8 +92,9 @@ VRM_API int vrm_draw(vrm_ctx *ctx, const vrm_camera_uniform *camera, vrm_image *
  * frame at a time).  cameras[i] renders into targets[i]; all targets must have the same size. */
 VRM_API int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets);
 
-/* vrm_draw_batch for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  NO COUNTERPART IN THE REFERENCE (wgpu allocates its command buffers and staging per frame).  Same arguments,
+/* vrm_draw_batch for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc.  (NOT a graph-capture
+ * entry point: the ABI exposes no stream to capture on, the descriptors are staged through a pinned ring whose slots later
+ * calls reuse, and once every 4096 views the call waits for the stream before the ring wraps.)  NO COUNTERPART IN THE REFERENCE (wgpu allocates its command buffers and staging per frame).  Same arguments,
  * same kernels, same image as vrm_draw_batch; the difference is where the march kernel's scratch -- the per-view
  * descriptors (inverse view-projection, position, output pointers; 120 B per view) -- lives: in a file-scope device array
  * of the library (30 KiB per GPU, held until the process ends) instead of the ring vrm_create allocated.  The call itself

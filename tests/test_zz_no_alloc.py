@@ -82,3 +82,29 @@ def test_static_draw_limits_and_errors(vr, orc):
     for im in imgs:
         im.close()
     r.close()
+
+
+def test_static_draw_across_a_wrap_of_the_descriptor_ring(vr, orc):
+    """the pinned descriptor ring holds 4096 views; 18 maximum-size static calls wrap it once (the call then waits
+    for the stream before reusing the slots).  The image of every call must still be its own cameras'."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    R = 16
+    r = vr.RayMarcher(0, R, R)
+    r.voxel_grid.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32((24, 20, 28))))
+    r.voxel_grid.attenuation = 40.0
+    r.voxel_grid.update_voxel_grid_buffer()
+    views = orc.sphere_views(4, 4)
+    cams = [vr.uniform_from_array(sphere_cam(orc, ix, iy, xdiv=4, ydiv=4)) for ix, iy in views]
+    want = _images(vr, r, len(cams), R)
+    r.draw_batch(cams, want)
+    want_px = [im.read() for im in want]
+    imgs = _images(vr, r, 256, R)
+    for call in range(18):                                         # 18 * 256 = 4608 views > 4096 slots
+        k = call % len(cams)
+        r.draw_batch_static([cams[(k + i) % len(cams)] for i in range(256)], imgs)
+        for i in (0, 100, 255):
+            assert np.array_equal(imgs[i].read(), want_px[(k + i) % len(cams)]), (call, i)
+    for im in want + imgs:
+        im.close()
+    r.close()
