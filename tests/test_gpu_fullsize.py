@@ -1,4 +1,5 @@
-"""BASELINE.json's full sizes on the GPU: C3 (512^3 RGBA, 1024^2) and one C4 view (1024^3 scalar, 2048^2).
+"""BASELINE.json's full sizes on the GPU: C1 (128^3 DAT file, one 512^2 view), C2, C3 (512^3 RGBA, 1024^2), one C4 view (1024^3
+scalar, 2048^2) and one rank's share of C5.
 Whole views against the oracle (about a second of 16 CPU threads each at C3), plus the size-independent properties:
 skipping on/off bit-identical, baseline kernel vs LDS kernel within 1 LSB, per-ray iteration counts summing to the
 reference-equivalent sample count, sort-last over 4 slabs equal to the unpartitioned render."""
@@ -98,6 +99,42 @@ def test_c4_one_view_against_oracle(vr, orc):
     m = image_metrics(got, ref["rgba8"])
     assert m["max"] <= 1 and m["rmse_norm"] < 1e-3, m
     assert (ref["rgba8"][..., 3] > 0).mean() > 0.1
+
+
+def test_c1_dat_volume_one_view(vr, orc, tmp_path):
+    """BASELINE.json configs[0]: synthetic 128^3 uint8 DAT volume, ONE 512 x 512 view -- (ix, iy) = (1, 3) of the 8 x 8 sphere at
+    radius 2.5, attenuation 1 (what every load resets it to, grid.rs:197), transfer function off -- read from DAT + RAW files on
+    disk the way loaders/dat.rs:10-82 reads them (header keys, x fastest, UCHAR replicated to [b,b,b,b]), rendered by the
+    HIP path and held to the oracle: <= 1 LSB, normalised RMSE < 1e-3, the oracle's iteration count per ray, skipping on/off
+    bit-identical."""
+    D, R = 128, 512
+    dens = synth.blobs_scalar_u8((D, D, D))
+    (tmp_path / "c1.raw").write_bytes(dens.tobytes())
+    (tmp_path / "c1.dat").write_text(f"ObjectFileName: c1.raw\nResolution: {D} {D} {D}\nSliceThickness: 1 1 1\nFormat: UCHAR\n")
+    r = vr.RayMarcher(0, R, R)
+    r.voxel_grid.attenuation = 7.0                                # a load must reset this (grid.rs:100,197)
+    r.voxel_grid.update_voxel_grid_buffer()
+    r.load_dat(str(tmp_path / "c1.dat"))
+    assert r.voxel_grid.dimensions == (D, D, D)
+    vox = np.repeat(dens[..., None], 4, axis=3)                   # [b,b,b,b] (dat.rs:74)
+    assert np.array_equal(r.voxel_grid.download_rgba8(), vox)
+    cam = sphere_cam(orc, 1, 3, xdiv=8, ydiv=8)
+    ref = orc.render(vox, cam, R, R, want_f32=False, want_steps=True)   # attenuation 1.0, TF off: the oracle's defaults
+    assert (ref["rgba8"][..., 3] > 0).mean() > 0.1
+    got = _render(r, vr, [cam], R)[0]
+    m = image_metrics(got, ref["rgba8"])
+    assert m["max"] <= 1 and m["rmse_norm"] < 1e-3, m
+    r.set_option(vr.OPT_DIAGNOSTICS, 1)
+    img = vr.Screenshotter(r, R, R)
+    r.draw(vr.uniform_from_array(cam), img)
+    _, iters = img.diagnostics()
+    assert np.array_equal(iters, ref["steps"])                    # loop iterations per ray == the oracle's
+    assert np.array_equal(img.read(), got)
+    img.close()
+    r.set_option(vr.OPT_DIAGNOSTICS, 0)
+    r.set_option(vr.OPT_SKIP_EMPTY, 0)
+    assert np.array_equal(_render(r, vr, [cam], R)[0], got)
+    r.close()
 
 
 def test_c2_full_size(vr, orc):
