@@ -24,6 +24,45 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def kernel_source_sha(root=ROOT):
+    """sha256 (first 16 hex digits) over the sources the march kernel is built from: what a profiles/traffic.json entry was
+    measured on, and what the in-tree library should have been built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("vrm_kernels.hip", "vrm_device.h"):
+        with open(os.path.join(root, "volume_renderer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_lookup(key, views_per_launch, root=ROOT):
+    """(traffic bytes per launch, secondary ceilings, traffic_source) for the roofline object.  HBM-side bytes cannot be
+    counted live (PMC needs rocprofv3 around the process): they come from the committed counter passes of the same workload
+    (profiles/traffic.json, written by tools/install_profiles.py with the sha of the kernel sources they were measured on).
+    An entry measured on OTHER kernel sources than the tree's is not reported: traffic and secondary are null and
+    traffic_source says why."""
+    src = {"file": "profiles/traffic.json", "key": key, "kernel_sha_built": None, "kernel_sha_measured": None, "measured": None,
+           "match": False, "reason": None}
+    try:
+        src["kernel_sha_built"] = kernel_source_sha(root)
+        tj = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    except (OSError, ValueError) as e:
+        src["reason"] = f"profiles/traffic.json or the kernel sources could not be read ({e.__class__.__name__})"
+        return None, None, src
+    ent = tj.get(key)
+    if not isinstance(ent, dict) or "hbm_bytes_per_view" not in ent:
+        src["reason"] = "no counter pass committed for this workload"
+        return None, None, src
+    src["kernel_sha_measured"] = ent.get("kernel_sha")
+    src["measured"] = ent.get("measured")
+    src["passes"] = ent.get("source")
+    if ent.get("kernel_sha") != src["kernel_sha_built"]:
+        src["reason"] = "the committed counter pass was measured on other kernel sources than this tree's"
+        return None, None, src
+    src["match"] = True
+    return int(ent["hbm_bytes_per_view"] * views_per_launch), ent.get("secondary"), src
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks as a CHILD
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` (one process per GPU,
@@ -62,9 +101,10 @@ def launcher_selftest(a):
     vd.barrier()
     t = vd.max_over_ranks(1.0 + rank)
     n = vd.sum_over_ranks(len(vd.partition_views(256, rank, world)))
+    per_rank = vd.gather_over_ranks(1.0 + rank)
     if rank == 0:
         print(json.dumps({"launcher_selftest": True, "n_gpus": world, "max_time": t, "views": int(n), "steps": a.steps,
-                          "warmup": a.warmup}), flush=True)
+                          "warmup": a.warmup, "per_rank": per_rank}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -401,10 +441,13 @@ def main():
     rm.synchronize()             # compute stream and copy stream of the library
     torch.cuda.synchronize()
     vd.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = vd.max_over_ranks(elapsed, coll_dev)
+    elapsed_mine = time.perf_counter() - t0
+    elapsed = vd.max_over_ranks(elapsed_mine, coll_dev)
     kernel_ms, launches = rm.profile_read()
     rm.set_option(vr.OPT_PROFILE, 0)
+    # per-rank spread, so that a bad N-GPU point can be attributed: every rank's own wall time and kernel time
+    per_rank_ms = vd.gather_over_ranks(elapsed_mine / a.steps * 1e3, coll_dev)
+    per_rank_kernel_ms = vd.gather_over_ranks(kernel_ms / a.steps, coll_dev)
     n_ref = vd.sum_over_ranks(n_ref_mine, coll_dev)
 
     # the same export with skipping off (every reference sample actually taken), one step, for transparency
@@ -446,25 +489,14 @@ def main():
     b_alg_view = D * D * D * vox_bytes + R * R * 4
     views_timed = len(my_cams) * a.steps
     achieved = (b_alg_view * views_timed / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else 0.0
-    # HBM-side bytes per launch cannot be counted live (PMC needs rocprofv3 around the process): the figure comes
-    # from the committed counter passes of the same workload (profiles/*/traffic.json: 2*FETCH_SIZE + WRITE_SIZE
-    # per view, gfx950 correction as in MI355X_MICROARCH.md), scaled to the views of one launch; null if none.
-    traffic, secondary = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}" + (":tf" if a.tf else "")
-        if key in tj:
-            traffic = int(tj[key]["hbm_bytes_per_view"] * B)
-            # SURVEY 8d's secondary ceilings and cache rates of the same kernel on the same workload, from the committed
-            # rocprofv3 PMC passes (formulas: DESIGN.md 4.3; tools/install_profiles.py computes them from profiles/rN/*.txt)
-            secondary = tj[key].get("secondary")
-    except (OSError, ValueError, KeyError):
-        traffic, secondary = None, None
+    key = f"{a.config}:kernel{a.kernel}:skip{a.skip_empty}" + (":tf" if a.tf else "")
+    traffic, secondary, traffic_source = traffic_lookup(key, B)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "kernel": "march kernel (variant %d)" % a.kernel, "launches": int(launches),
                 "avg_launch_ms": round(kernel_ms / max(1, launches), 4),
-                "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B, "secondary": secondary}
+                "algorithmic_bytes_per_view": b_alg_view, "views_per_launch": B, "secondary": secondary,
+                "traffic_source": traffic_source}
     # SURVEY.md 8(d) prices the voxels in the INPUT file's format (f32 RGBA = 16 B, f32 scalar = 4 B); the kernel
     # reads the RGBA8 texels the reference's own texture holds (4 B; 1 B for the 1-channel march), so `achieved` and
     # `frac` above use those (the lower figures). The survey-priced pair is carried beside them so either convention
@@ -489,7 +521,12 @@ def main():
         "executed_samples_per_step": int(n_exec), "executed_empty_samples_per_step": int(n_exec_zero),
         "chunks_per_step": chunk_stats,
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
-        "volume_broadcast_ms": round(bcast_ms, 2), "rccl_ranks": 0 if (rehearse or world == 1) else world, "roofline": roofline,
+        "ms_per_step_min": round(min(per_rank_ms), 3), "ms_per_step_max": round(max(per_rank_ms), 3),
+        "per_rank": {"ms_per_step": [round(v, 3) for v in per_rank_ms], "kernel_ms_per_step": [round(v, 3) for v in per_rank_kernel_ms],
+                     "views": [len(vd.partition_views(n_views, r_, world)) for r_ in range(world)]},
+        "volume_broadcast_ms": round(bcast_ms, 2),
+        "volume_broadcast_gbs": round(D * D * D * 4 / (bcast_ms * 1e-3) / 1e9, 2) if bcast_ms > 0 else None,
+        "rccl_ranks": 0 if (rehearse or world == 1) else world, "roofline": roofline,
         "views_per_s_no_skip": None if no_skip is None else round(no_skip, 3),
     }
 

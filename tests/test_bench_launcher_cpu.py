@@ -32,6 +32,7 @@ def test_gpus_n_spawns_n_ranks_and_prints_one_line(n):
     assert out["n_gpus"] == n and out["launcher_selftest"] is True
     assert out["max_time"] == float(n) and out["views"] == 256     # max over ranks of 1 + rank; the partition covers every view
     assert out["steps"] == 2 and out["warmup"] == 1                 # the arguments reached the ranks unchanged
+    assert out["per_rank"] == [float(r + 1) for r in range(n)]       # the per-rank spread of the bench line, in rank order
 
 
 def test_single_rank_does_not_spawn():
@@ -46,3 +47,30 @@ def test_world_size_mismatch_is_an_error():
     p = _run(["--gpus", "4"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0
     assert "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_traffic_counters_are_reported_only_for_the_kernel_they_were_measured_on(tmp_path):
+    """roofline.traffic / roofline.secondary come from committed rocprofv3 passes; an entry measured on other
+    kernel sources than the tree's must not be replayed as if it were this kernel's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    root = tmp_path
+    os.makedirs(root / "volume_renderer_amd" / "csrc")
+    os.makedirs(root / "profiles")
+    (root / "volume_renderer_amd" / "csrc" / "vrm_kernels.hip").write_text("kernel v1")
+    (root / "volume_renderer_amd" / "csrc" / "vrm_device.h").write_text("structs v1")
+    sha = bench.kernel_source_sha(str(root))
+    entry = {"hbm_bytes_per_view": 1000, "kernel_sha": sha, "measured": "2026-11-11", "source": "profiles/r3/x.txt", "secondary": {"valu_issue_frac": 0.9}}
+    (root / "profiles" / "traffic.json").write_text(json.dumps({"C3:kernel1:skip1": entry}))
+    traffic, secondary, src = bench.traffic_lookup("C3:kernel1:skip1", 32, str(root))
+    assert traffic == 32000 and secondary == {"valu_issue_frac": 0.9}
+    assert src["match"] is True and src["kernel_sha_built"] == src["kernel_sha_measured"] == sha and src["measured"] == "2026-11-11"
+    (root / "volume_renderer_amd" / "csrc" / "vrm_kernels.hip").write_text("kernel v2")      # the kernel changed after the pass
+    traffic, secondary, src = bench.traffic_lookup("C3:kernel1:skip1", 32, str(root))
+    assert traffic is None and secondary is None and src["match"] is False
+    assert src["kernel_sha_built"] != sha and "other kernel sources" in src["reason"]
+    traffic, secondary, src = bench.traffic_lookup("C9:kernel1:skip1", 32, str(root))          # no pass for this workload
+    assert traffic is None and "no counter pass" in src["reason"]
+    # the committed file and the tree: whatever the state, the lookup answers with a reasoned source
+    _, _, src = bench.traffic_lookup("C3:kernel1:skip1", 32)
+    assert src["kernel_sha_built"] and (src["match"] or src["reason"])

@@ -7,9 +7,10 @@ import os
 import re
 import shutil
 import sys
+import time
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
 N_SIMD, N_CU = 1024, 256   # MI355X: 256 CUs x 4 SIMDs
 O, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
@@ -18,11 +19,14 @@ for f in ["bench_final_c3.json", "bench_final_c3_under_rocprofv3.json", "bench_f
     if os.path.exists(os.path.join(O, f)):
         shutil.copy(os.path.join(O, f), os.path.join(P, f))
 passes = {"final_c3_skip1": ("pmc_final_skip1.txt", 32, "C3:kernel1:skip1"), "final_c3_skip0": ("pmc_final_skip0.txt", 32, "C3:kernel1:skip0"),
-          "final_c4_skip1": ("pmc_final_c4_skip1.txt", 16, "C4:kernel1:skip1"), "final_c2_skip1": ("pmc_final_c2_skip1.txt", 32, "C2:kernel1:skip1")}
+          "final_c4_skip1": ("pmc_final_c4_skip1.txt", 16, "C4:kernel1:skip1"), "final_c2_skip1": ("pmc_final_c2_skip1.txt", 32, "C2:kernel1:skip1"),
+          "final_c3tf_skip1": ("pmc_final_c3tf_skip1.txt", 32, "C3:kernel1:skip1:tf")}
 tj_path = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(tj_path))
 for tag, (name, views, key) in passes.items():
     src = os.path.join(ROOT, "gpurun_out", "prof", tag, "summary.txt")
+    if not os.path.exists(src):
+        continue
     shutil.copy(src, os.path.join(P, name))
     s = open(src).read()
     blk = s[s.index("== counters: void march_lds_kernel"):]
@@ -34,6 +38,9 @@ for tag, (name, views, key) in passes.items():
     ms = max(prod, key=lambda m: float(m.group(5))).group(6)
     t.setdefault(key, {})["hbm_bytes_per_view"] = int((2 * f + w) * 1024 / views)
     t[key]["source"] = f"profiles/{rnd}/{name} ({views} views per launch)"
+    # what the pass was measured on: tools/final_profiles.sh writes the sha of the kernel sources of the tree it ran from
+    t[key]["kernel_sha"] = open(os.path.join(ROOT, "gpurun_out", "final", "kernel_sha.txt")).read().strip()
+    t[key]["measured"] = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(src)))
     print(key, t[key]["hbm_bytes_per_view"], "B/view, kernel", ms, "ms per launch")
 
     # SURVEY 8d's secondary ceilings (DESIGN.md 4.3 states the formulas); every input is a per-dispatch mean of that file

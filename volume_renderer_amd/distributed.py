@@ -71,3 +71,16 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value, device="cpu"):
+    """every rank's value, in rank order, on every rank (the per-rank spread of the bench line)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
