@@ -21,6 +21,9 @@
 #ifndef VRM_CAP_PACKED
 #define VRM_CAP_PACKED VRM_CAP_DEFAULT /* LDS words per wave of the packed 1-channel march */
 #endif
+#ifndef VRM_WEIGHTS_FIRST
+#define VRM_WEIGHTS_FIRST 0 /* A/B: trilinear filter of the RGBA march as eight corner weights + byte * weight products */
+#endif
 #ifndef VRM_SKIP_MAX_LEVEL
 #define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
 #endif
@@ -181,6 +184,33 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     // (tools/probes/valu_probe.hip: values exact, the FMA runs at full rate with a denormal operand).  Per x-lerp
     // that is sub_sdwa + mul_sdwa + fma instead of two conversions, a subtraction and an FMA.
     const float wxs = wx * 0x1p127f;
+#if VRM_WEIGHTS_FIRST
+    // A/B form: the eight corner weights once per sample (shared by the channels), then per channel eight
+    // byte * weight products -- the SDWA multiply converts and scales in one instruction -- and an add tree.  gfx950 has no
+    // multiply-accumulate with a byte-selected operand (v_mac/v_fmac_f32_sdwa do not assemble), so the accumulate is a
+    // separate add.
+    float W[8];
+    {
+        const float w11 = wx * wy, w10 = wx - w11, w01 = wy - w11, w00 = (1.0f - wx) - w01; // (x,y) = (1,1), (1,0), (0,1), (0,0)
+        const float z1 = wz * 0x1p127f;
+        W[4] = w00 * z1; W[5] = w10 * z1; W[6] = w01 * z1; W[7] = w11 * z1;
+        W[0] = __builtin_fmaf(w00, 0x1p127f, -W[4]); W[1] = __builtin_fmaf(w10, 0x1p127f, -W[5]);
+        W[2] = __builtin_fmaf(w01, 0x1p127f, -W[6]); W[3] = __builtin_fmaf(w11, 0x1p127f, -W[7]);
+    }
+    auto tri = [&](auto kc) -> float {
+        constexpr int k = decltype(kc)::value;
+        auto bw = [&](uint32_t t, float w) -> float {
+            float r;
+            if constexpr (k == 0) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(t), "v"(w));
+            if constexpr (k == 1) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(t), "v"(w));
+            if constexpr (k == 2) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(t), "v"(w));
+            if constexpr (k == 3) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(t), "v"(w));
+            return r;
+        };
+        return ((bw(c[0], W[0]) + bw(c[1], W[1])) + (bw(c[2], W[2]) + bw(c[3], W[3]))) +
+               ((bw(c[4], W[4]) + bw(c[5], W[5])) + (bw(c[6], W[6]) + bw(c[7], W[7])));
+    };
+#else
     auto tri = [&](auto kc) -> float {
         constexpr int k = decltype(kc)::value;
         const float a00 = byte_scaled<k>(c[0]), a10 = byte_scaled<k>(c[2]), a01 = byte_scaled<k>(c[4]), a11 = byte_scaled<k>(c[6]);
@@ -192,6 +222,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
         return __builtin_fmaf(wz, c1 - c0, c0);
     };
+#endif
     const float a22 = tri(std::integral_constant<int, 3>{});
     if (a_out) *a_out = a22;
     // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a22 * kexp22)
