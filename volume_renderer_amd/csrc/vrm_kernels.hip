@@ -654,6 +654,11 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         aligned = slowest > 0.25f * smax;
     }
     const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
+    // the plane coordinate of a sample, prog(dt) = sgn * u_m(dt) = fma(dt, sgn * rs_m, sgn * bla_m) (negation commutes with
+    // rounding: bit-identical), from two per-lane registers chosen once per tile -- as a select on the major axis per chunk it
+    // was three FMAs, two v_cndmask and six v_readlane of spilled lane masks
+    const float rs_m = sgn * (m_axis == 0 ? rs[0] : m_axis == 1 ? rs[1] : rs[2]);
+    const float bla_m = sgn * (m_axis == 0 ? bla[0] : m_axis == 1 ? bla[1] : bla[2]);
     const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
     // Boxes from the tile's geometry.  The rays of a tile are a pencil through the camera: at plane coordinate p (along the
     // major axis, see `prog` below) lane l is at u_a = bla_a + (p - p_cam) * B_l[a], B_l[a] = rs_l[a] / |rs_l[m]|, and a
@@ -700,6 +705,9 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // empty costs one prologue and drops back to lvl 0, where chunks are staged and sampled.  How the march is cut into
     // chunks does not change what a sample contributes (see the steps below), so this is as exact as plain skipping.
     int lvl = 0, lvl_run = 0;
+    // byte offset of pyramid level L in lane L of one register (indexed by the level as an array of the kernel argument it is a
+    // scalar load and its round trip in every chunk prologue)
+    const uint32_t occ_off_v = lane == 1u ? g.occ_off[1] : lane == 2u ? g.occ_off[2] : lane == 3u ? g.occ_off[3] : 0u;
     const uint32_t lane_c0 = lane & 3u, lane_c1 = (lane >> 2) & 3u, lane_c2 = lane >> 4; // this lane's cell in an emptiness test
 
     // Per-wave chunk depth.  How deep a box fits the tile depends on the view direction through this tile (an oblique
@@ -711,9 +719,14 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // (dt, active, steps left) and the stride level alone, so it can be made for the NEXT chunk while the current chunk's
     // box is still in flight (look-ahead below).
     auto plan = [&](const float dt, const bool active, const int steps_left, const int lvl, ChunkPlan &q) __attribute__((always_inline)) {
-        float ua[3];
-        texel_coord(dt, ua); // (the formula the samples are filtered at)
-        const float prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
+        float ua[3] = {0.0f, 0.0f, 0.0f};
+        float prog;
+        if (far_cam) {
+            texel_coord(dt, ua); // (the formula the samples are filtered at)
+            prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
+        } else {
+            prog = __builtin_fmaf(dt, rs_m, bla_m);
+        }
         const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
         // chunk length = the steps of the rear-most lane: the wave's learned depth for plain chunks, strides in empty space
         int kk = lvl > 0 ? (int)P.chunk_steps << lvl : kk_base;
@@ -764,7 +777,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                       ncz = (min(ihi[2], mxz) >> sh) - c0z + 1;
             const uint32_t rnd = (1u << lvl) - 1u;
             const uint32_t od0 = (g.occ_dim[0] + rnd) >> lvl, od1 = (g.occ_dim[1] + rnd) >> lvl;
-            const uint8_t *occl = g.occ + g.occ_off[lvl];
+            const uint8_t *occl = g.occ + (uint32_t)__builtin_amdgcn_readlane((int)occ_off_v, uni(lvl));
             if (ncx <= 4 && ncy <= 4 && ncz <= 4) {
                 // the usual case: the cells are a corner of the 4x4x4 block the lanes stand for (lane = x + 4*y + 16*z), one
                 // byte per lane at a lane-constant offset from the block's first cell (a level fits 32-bit offsets)
@@ -816,6 +829,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         for (;;) {
             if (use_geo) interior = geo_box(kk, ilo, ihi);
             else {
+                if (!far_cam) texel_coord(dt, ua); // (only the reduction over the lanes' own positions needs all three axes)
                 n_lane = lane_steps(kk);
                 interior = chunk_box(n_lane, ilo, ihi); // every step of every lane stays inside the volume (slab) with margin
             }
@@ -829,7 +843,8 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             slice = ny * pitch;
             slice += (slice & 4) ? 0 : 4;
             // (PACKED reads the word after a sample's word as well: keep one word of the tile spare)
-            fits = !none && pitch <= PX_MAX && (long long)nz * slice + (PACKED ? 1 : 0) <= (long long)CAP;
+            // (ny, nz <= CAP first: the clamped bounds span up to 2^29 texels, and pitch <= 64, so the product then fits 32 bits)
+            fits = !none && pitch <= PX_MAX && ny <= CAP && nz <= CAP && nz * slice + (PACKED ? 1 : 0) <= CAP;
             if (fits || none || kk == 1 || lvl > 0) break; // (a deep empty-space probe is never staged: it need not fit)
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
             if (DIAG) ++st_retry;
@@ -841,6 +856,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                 kk = 8;
                 n_lane = active ? min(8, steps_left) : 0;
                 // the box above is that of the ONE step that did not fit; the emptiness test must cover all 8
+                if (!far_cam) texel_coord(dt, ua);
                 (void)chunk_box(n_lane, ilo, ihi);
             }
             if (SKIP) empty = box_is_empty();
@@ -896,7 +912,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         bool empty = cp.empty;
         if (lvl == 0 && fits) {
             if (kk < kk_base) kk_base = kk;
-            else if ((long long)nz * slice * 5 < (long long)CAP * 4 && 2 * kk_base < 3 * (int)P.chunk_steps) kk_base += max(1, kk_base >> 3);
+            else if (nz * slice * 5 < CAP * 4 && 2 * kk_base < 3 * (int)P.chunk_steps) kk_base += max(1, kk_base >> 3);
         }
         if (DIAG) ++st_chunks;
         if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
@@ -1056,7 +1072,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             active = active && steps_left > 0;
             if (SKIP && VRM_SKIP_MAX_LEVEL > 0) {
                 // (level L exists only if the pyramid fits 32-bit offsets: occ_off[L] != 0)
-                if (++lvl_run >= VRM_SKIP_ESCALATE && lvl < VRM_SKIP_MAX_LEVEL && g.occ_off[lvl + 1] != 0u) { ++lvl; lvl_run = 0; }
+                if (++lvl_run >= VRM_SKIP_ESCALATE && lvl < VRM_SKIP_MAX_LEVEL && __builtin_amdgcn_readlane((int)occ_off_v, uni(lvl + 1)) != 0) { ++lvl; lvl_run = 0; }
             }
             continue;
         }
