@@ -224,6 +224,9 @@ VRM_API int vrm_comm_destroy(vrm_ctx *ctx);
  * take the STORED slices only (x*y*(stored) voxels, slice order ascending).  Resets attenuation/TF like
  * vrm_grid_resize. */
 VRM_API int vrm_grid_resize_slab(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t z_begin, uint32_t z_end);
+/* device bytes the current grid holds (voxel copies, bricks, occupancy pyramid): 9 B/voxel for an RGBA volume, about 1 B/voxel
+ * for a scalar one in its compact form (VRM_OPT_COMPACT_SCALAR).  No reference counterpart (a wgpu texture's size is implied). */
+VRM_API int vrm_grid_resident_bytes(vrm_ctx *ctx, size_t *bytes);
 /* stored slice range and owned slice range of the current grid ([0,z) twice for an unpartitioned grid) */
 VRM_API int vrm_grid_get_slab(vrm_ctx *ctx, uint32_t *z_store_begin, uint32_t *z_store_end, uint32_t *z_begin, uint32_t *z_end);
 
@@ -287,9 +290,14 @@ typedef enum vrm_option {
     VRM_OPT_PROFILE = 2,      /* default 0; 1: record hipEvents around every march launch (vrm_profile_read) */
     VRM_OPT_DIAGNOSTICS = 3,  /* default 0; 1: also write per-pixel f32 colour, iteration counts and ray geometry */
     VRM_OPT_CHUNK_STEPS = 4,  /* default 0 = automatic; n: march steps per LDS-staged box (tuning, no effect on the image) */
-    VRM_OPT_PACKED_ALPHA = 5  /* 1-channel march (scalar volumes, transfer function) staged from the packed alpha copy of
+    VRM_OPT_PACKED_ALPHA = 5, /* 1-channel march (scalar volumes, transfer function) staged from the packed alpha copy of
                                  the volume, one byte per texel: 1 = on (default), 0 = stage the RGBA8 texels instead (tuning; same
                                  image to f32 rounding) */
+    VRM_OPT_COMPACT_SCALAR = 6 /* default 1: after an upload that turned out scalar (r == g == b == a in every voxel: DAT files,
+                                 1-channel f32) keep only what the 1-channel march reads -- packed alpha bricks + occupancy pyramid,
+                                 about 1 B/voxel -- and release the 8 B/voxel of RGBA8 copies; they are rebuilt (exactly) when a
+                                 download, a broadcast, the voxel compare or an RGBA-staging kernel option needs them.  0: keep
+                                 everything resident (9 B/voxel).  Takes effect at the next upload. */
 } vrm_option;
 VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
 VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);

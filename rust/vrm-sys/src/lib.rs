@@ -42,6 +42,7 @@ pub const VRM_OPT_PROFILE: c_int = 2;
 pub const VRM_OPT_DIAGNOSTICS: c_int = 3;
 pub const VRM_OPT_CHUNK_STEPS: c_int = 4;
 pub const VRM_OPT_PACKED_ALPHA: c_int = 5;
+pub const VRM_OPT_COMPACT_SCALAR: c_int = 6;
 
 extern "C" {
     // RayMarcher (ray_marcher/mod.rs:18-142)
@@ -83,6 +84,7 @@ extern "C" {
     pub fn vrm_netcdf_write_color(path: *const c_char, x: u32, y: u32, z: u32, color_czyx: *const f32) -> c_int;
     // sort-last rendering of a z-slab-partitioned volume
     pub fn vrm_grid_resize_slab(ctx: *mut vrm_ctx, x: u32, y: u32, z: u32, z_begin: u32, z_end: u32) -> c_int;
+    pub fn vrm_grid_resident_bytes(ctx: *mut vrm_ctx, bytes: *mut usize) -> c_int;
     pub fn vrm_grid_get_slab(ctx: *mut vrm_ctx, z_store_begin: *mut u32, z_store_end: *mut u32, z_begin: *mut u32, z_end: *mut u32) -> c_int;
     pub fn vrm_draw_partial(ctx: *mut vrm_ctx, cameras: *const vrm_camera_uniform, n: u32, width: u32, height: u32,
                             rgba_f32_device: *mut f32) -> c_int;

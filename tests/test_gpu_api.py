@@ -419,3 +419,84 @@ def test_library_broadcast_single_rank(vr, orc):
     r.comm_destroy()          # idempotent
     img.close()
     r.close()
+
+
+def test_scalar_volume_is_held_compact_and_expands_on_demand(vr, orc):
+    """a scalar volume keeps what the 1-channel march reads -- packed alpha bricks + pyramid, about 1 B/voxel --
+    and drops the 8 B/voxel of RGBA copies; anything that needs them (download, RGBA-staging kernel options, the compare) gets
+    them back exactly.  Dims off every brick boundary, so the edge-staging path (which used to read the RGBA copy) is on."""
+    dims = (45, 38, 51)                                              # x, y, z
+    n = dims[0] * dims[1] * dims[2]
+    dens = synth.blobs_scalar_u8(dims)                              # (Z, Y, X)
+    R = 96
+    cams = [vr.uniform_from_array(sphere_cam(orc, ix, iy)) for ix, iy in ((1, 3), (5, 6), (0, 1))]
+
+    def render(r):
+        imgs = [vr.Screenshotter(r, R, R) for _ in cams]
+        r.draw_batch(cams, imgs)
+        out = [im.read() for im in imgs]
+        for im in imgs:
+            im.close()
+        return out
+
+    full = vr.RayMarcher(0, R, R)
+    full.set_option(vr.OPT_COMPACT_SCALAR, 0)
+    full.voxel_grid.new(dims)
+    full.voxel_grid.upload_scalar(dens.reshape(-1), dims, 1)
+    assert full.voxel_grid.resident_bytes() >= 9 * n
+    want = render(full)
+    assert any(w[..., 3].any() for w in want)
+
+    r = vr.RayMarcher(0, R, R)
+    r.voxel_grid.new(dims)
+    assert r.voxel_grid.resident_bytes() >= 9 * n                   # default voxels [0,0,0,255] are not scalar
+    r.voxel_grid.upload_scalar(dens.reshape(-1), dims, 1)
+    compact = r.voxel_grid.resident_bytes()
+    assert compact < 2.2 * n, (compact, n)                           # packed bricks (padded to 16 x 4 x 2) + pyramid
+    got = render(r)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)                                  # the same march from the same bytes
+    assert r.voxel_grid.resident_bytes() == compact                  # the default draw needed nothing else
+    ref = orc.render(np.repeat(dens[..., None], 4, axis=3), sphere_cam(orc, 1, 3), R, R, want_f32=False)
+    assert image_metrics(got[0], ref["rgba8"])["max"] <= 1
+    # the transfer function on the compact volume (still the packed march)
+    r.voxel_grid.set_transfer_function_active(True)
+    r.voxel_grid.update_transfer_function_buffer()
+    full.voxel_grid.set_transfer_function_active(True)
+    full.voxel_grid.update_transfer_function_buffer()
+    for a, b in zip(render(r), render(full)):
+        assert np.array_equal(a, b)
+    assert r.voxel_grid.resident_bytes() == compact
+    r.voxel_grid.set_transfer_function_active(False)
+    r.voxel_grid.update_transfer_function_buffer()
+    # the allocation-free draw may not expand: a clear error when the options need the RGBA copies
+    imgs = [vr.Screenshotter(r, R, R) for _ in cams]
+    r.draw_batch_static(cams, imgs)                                  # default options: fine
+    assert np.array_equal(imgs[0].read(), want[0])
+    r.set_option(vr.OPT_PACKED_ALPHA, 0)
+    with pytest.raises(vr.VrmError) as e:
+        r.draw_batch_static(cams, imgs)
+    assert "compact" in str(e.value)
+    for im in imgs:
+        im.close()
+    # RGBA-staged 1-channel march: expands, same image to rounding
+    staged = render(r)
+    assert r.voxel_grid.resident_bytes() >= 9 * n
+    for a, b in zip(staged, want):
+        assert image_metrics(a, b)["max"] <= 1
+    r.set_option(vr.OPT_PACKED_ALPHA, 1)
+    # a new upload compacts again; download gives [b,b,b,b] back exactly (and expands); the baseline kernel works after it
+    r.voxel_grid.upload_scalar(dens.reshape(-1), dims, 1)
+    assert r.voxel_grid.resident_bytes() == compact
+    vox = r.voxel_grid.download_rgba8()
+    assert np.array_equal(vox, np.repeat(dens[..., None], 4, axis=3))
+    r.voxel_grid.upload_scalar(dens.reshape(-1), dims, 1)
+    r.set_option(vr.OPT_KERNEL, 0)
+    for a, b in zip(render(r), want):
+        assert image_metrics(a, b)["max"] <= 1
+    r.set_option(vr.OPT_KERNEL, 1)
+    # an RGBA volume is never compacted
+    r.voxel_grid.upload_rgba8(synth.quantize_rgba8(synth.blobs_rgba_f32(dims)))
+    assert r.voxel_grid.resident_bytes() >= 9 * n
+    full.close()
+    r.close()

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import (CameraUniform, GridUniform, TransferFunction, VrmError, OPT_CHUNK_STEPS, OPT_DIAGNOSTICS, OPT_KERNEL,
-                   OPT_PACKED_ALPHA, OPT_PROFILE, OPT_SKIP_EMPTY)
+                   OPT_COMPACT_SCALAR, OPT_PACKED_ALPHA, OPT_PROFILE, OPT_SKIP_EMPTY)
 
 __all__ = ["RayMarcher", "VoxelGrid", "Screenshotter", "Camera", "CameraSphereController", "SphereScreenshotManager",
            "CameraUniform", "TransferFunction", "GridUniform", "VrmError", "sphere_views"]
@@ -167,6 +167,12 @@ class VoxelGrid:
         if tuple(dimensions) != tuple(self.dimensions):
             self.new(dimensions)
         _ffi.check(_ffi.lib().vrm_grid_upload_scalar(self._rm._h, r.ctypes.data, r.nbytes, bytes_per_sample))
+
+    def resident_bytes(self):
+        """device bytes the grid holds (vrm_grid_resident_bytes): 9 B/voxel, or about 1 B/voxel for a compact scalar volume"""
+        n = ctypes.c_size_t()
+        _ffi.check(_ffi.lib().vrm_grid_resident_bytes(self._rm._h, ctypes.byref(n)))
+        return int(n.value)
 
     def download_rgba8(self):
         x, y, _ = (int(d) for d in self.uniform().dimensions[:3])

@@ -19,6 +19,7 @@ OPT_PROFILE = 2
 OPT_DIAGNOSTICS = 3
 OPT_CHUNK_STEPS = 4
 OPT_PACKED_ALPHA = 5
+OPT_COMPACT_SCALAR = 6
 
 
 class VrmError(RuntimeError):
@@ -101,6 +102,7 @@ SYMBOLS = {
     "vrm_netcdf_write_color": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "vrm_grid_resize_slab": (ctypes.c_int, [_vp] + [ctypes.c_uint32] * 5),
     "vrm_grid_get_slab": (ctypes.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
+    "vrm_grid_resident_bytes": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
     "vrm_draw_partial": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "vrm_composite": (ctypes.c_int, [_vp, ctypes.POINTER(CameraUniform), _vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_uint32, ctypes.c_uint32, _vp, _vp]),

@@ -104,6 +104,53 @@ static void grid_free(vrm_ctx *ctx)
     ctx->vox_words = 0;
 }
 
+// ---- compact form of a scalar volume -------------------------------------------------------------
+// A scalar volume (r == g == b == a in every voxel: DAT files, 1-channel f32) is marched from its packed alpha bricks and
+// the occupancy pyramid alone -- 1 B/voxel -- so after an upload that turned out scalar the x-fastest RGBA8 copy and the RGBA
+// bricks (8 B/voxel) are released.  They come back on demand (grid_expand: [b,b,b,b] from the alpha bricks, exact) when
+// something needs them: a download, a broadcast, the voxel-space compare, or a draw with a kernel that stages RGBA texels.
+static size_t rgba_bricks_bytes(const uint32_t d[3]) { return (size_t)((d[0] + 3) / 4) * ((d[1] + 3) / 4) * ((d[2] + 1) / 2) * 128; }
+
+// storage for the 4 B/voxel copies (contents undefined): what every upload writes into
+static int grid_rgba_storage(vrm_ctx *ctx)
+{
+    if (!ctx->vox) HIP_TRY(hipMalloc((void **)&ctx->vox, ctx->vox_words * 4));
+    if (!ctx->bricks) HIP_TRY(hipMalloc((void **)&ctx->bricks, rgba_bricks_bytes(ctx->dim)));
+    return VRM_OK;
+}
+
+static int grid_expand(vrm_ctx *ctx)
+{
+    if (ctx->vox && ctx->bricks) return VRM_OK;
+    REQUIRE(ctx->abricks != nullptr, "the context holds no voxel grid");
+    const bool had_vox = ctx->vox != nullptr;
+    int rc = grid_rgba_storage(ctx);
+    if (rc) return rc;
+    if (!had_vox) HIP_TRY(vrm_launch_expand_alpha_bricks(ctx->abricks, ctx->dim, ctx->vox, ctx->stream));
+    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
+    return VRM_OK;
+}
+
+int vrm_grid_expand_internal(vrm_ctx *ctx) { return grid_expand(ctx); }
+
+// does the march, as the options stand, read anything but the packed alpha bricks and the pyramid?
+static bool draw_needs_rgba(const vrm_ctx *ctx)
+{
+    const bool one_channel = ctx->scalar || ctx->tf.use_transfer_function[0] != 0;
+    return !(one_channel && ctx->opt_packed != 0 && (ctx->opt_kernel == 1 || ctx->opt_kernel == 3 || ctx->opt_kernel == 4));
+}
+
+static int grid_compact(vrm_ctx *ctx)
+{
+    if (!ctx->scalar || !ctx->opt_compact || draw_needs_rgba(ctx)) return VRM_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the builders of the packed bricks and of the pyramid read the RGBA copy
+    if (ctx->vox) (void)hipFree(ctx->vox);
+    if (ctx->bricks) (void)hipFree(ctx->bricks);
+    ctx->vox = nullptr;
+    ctx->bricks = nullptr;
+    return VRM_OK;
+}
+
 static int grid_alloc_buffers(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
 {
     const size_t words = (size_t)x * y * z;
@@ -111,7 +158,7 @@ static int grid_alloc_buffers(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
     HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
     uint32_t occ_off[VRM_OCC_LEVELS];
     HIP_TRY(hipMalloc((void **)&ctx->occ, vrm_occupancy_bytes(xyz, occ_off)));
-    HIP_TRY(hipMalloc((void **)&ctx->bricks, (size_t)((x + 3) / 4) * ((y + 3) / 4) * ((z + 1) / 2) * 128));
+    HIP_TRY(hipMalloc((void **)&ctx->bricks, rgba_bricks_bytes(xyz)));
     HIP_TRY(hipMalloc((void **)&ctx->abricks, vrm_alpha_bricks_bytes(xyz)));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
@@ -186,6 +233,19 @@ extern "C" int vrm_grid_resize_slab(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32
     ctx->slab_z0 = z_begin;
     ctx->slab_z1 = z_end;
     return grid_reset_contents(ctx);
+}
+
+extern "C" int vrm_grid_resident_bytes(vrm_ctx *ctx, size_t *bytes)
+{
+    REQUIRE(ctx != nullptr && bytes != nullptr, "null argument");
+    uint32_t off[VRM_OCC_LEVELS];
+    size_t n = 0;
+    if (ctx->vox) n += ctx->vox_words * 4;
+    if (ctx->bricks) n += rgba_bricks_bytes(ctx->dim);
+    if (ctx->abricks) n += vrm_alpha_bricks_bytes(ctx->dim);
+    if (ctx->occ) n += vrm_occupancy_bytes(ctx->dim, off);
+    *bytes = n;
+    return VRM_OK;
 }
 
 extern "C" int vrm_grid_get_slab(vrm_ctx *ctx, uint32_t *z_store_begin, uint32_t *z_store_end, uint32_t *z_begin, uint32_t *z_end)
@@ -280,7 +340,7 @@ static int grid_finish_upload(vrm_ctx *ctx)
     HIP_TRY(hipMemcpyAsync(&flag, ctx->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->scalar = (flag == 0);
-    return VRM_OK;
+    return grid_compact(ctx);
 }
 
 extern "C" int vrm_grid_upload_rgba8(vrm_ctx *ctx, const uint8_t *host_voxels, size_t nbytes)
@@ -289,6 +349,7 @@ extern "C" int vrm_grid_upload_rgba8(vrm_ctx *ctx, const uint8_t *host_voxels, s
     if (rc) return rc;
     REQUIRE(host_voxels != nullptr, "null voxel pointer");
     REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    if (int rc_ = grid_rgba_storage(ctx)) return rc_; // (a compact scalar volume released it)
     HIP_TRY(hipMemcpyAsync(ctx->vox, host_voxels, nbytes, hipMemcpyHostToDevice, ctx->stream));
     return grid_finish_upload(ctx);
 }
@@ -299,12 +360,14 @@ extern "C" int vrm_grid_upload_rgba8_device(vrm_ctx *ctx, const void *device_vox
     if (rc) return rc;
     REQUIRE(device_voxels != nullptr, "null voxel pointer");
     REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    if (int rc_ = grid_rgba_storage(ctx)) return rc_; // (a compact scalar volume released it)
     HIP_TRY(hipMemcpyAsync(ctx->vox, device_voxels, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
     return grid_finish_upload(ctx);
 }
 
 static int upload_f32_common(vrm_ctx *ctx, const float *dev_src, uint32_t channels)
 {
+    if (int rc_ = grid_rgba_storage(ctx)) return rc_; // (a compact scalar volume released it)
     HIP_TRY(vrm_launch_quantize_f32(dev_src, channels, ctx->vox_words, ctx->vox, ctx->stream));
     return grid_finish_upload(ctx);
 }
@@ -344,6 +407,7 @@ extern "C" int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, siz
     uint8_t *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, nbytes));
     rc = vrm_check_hip(hipMemcpyAsync(tmp, host_raw, nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+    if (!rc) rc = grid_rgba_storage(ctx);
     if (!rc) rc = vrm_check_hip(vrm_launch_quantize_scalar(tmp, bytes_per_sample, ctx->vox_words, ctx->vox, ctx->stream), "quantize");
     if (!rc) rc = grid_finish_upload(ctx);
     (void)hipStreamSynchronize(ctx->stream);
@@ -357,6 +421,7 @@ extern "C" int vrm_grid_download_rgba8(vrm_ctx *ctx, uint8_t *host_voxels, size_
     if (rc) return rc;
     REQUIRE(host_voxels != nullptr, "null voxel pointer");
     REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
+    if ((rc = grid_expand(ctx))) return rc; // a compact scalar volume: [b,b,b,b] back from the packed alpha bricks
     HIP_TRY(hipMemcpyAsync(host_voxels, ctx->vox, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VRM_OK;
@@ -667,9 +732,18 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
                 n, VRM_STATIC_MAX_VIEWS);
         REQUIRE(ctx->scratch != nullptr, "the descriptor scratch of device %d was not initialised", ctx->device);
     }
-    if (!ctx->vox) {
+    if (!ctx->abricks) {
         vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
         return VRM_ERR_STATE;
+    }
+    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx)) {
+        // a compact scalar volume and options that stage RGBA texels (VRM_OPT_KERNEL 0 / 2, VRM_OPT_PACKED_ALPHA 0): expand it
+        if (use_static) {
+            vrm_set_error("vrm_draw_batch_static: the scalar volume is held in its compact form and these options need the RGBA copies, "
+                          "which this entry point may not allocate (draw once with vrm_draw_batch, or keep the default kernel options)");
+            return VRM_ERR_STATE;
+        }
+        if ((rc = grid_expand(ctx))) return rc;
     }
     const uint32_t w = targets[0] ? targets[0]->width : 0, h = targets[0] ? targets[0]->height : 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -773,10 +847,11 @@ extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras,
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (!ctx->vox) {
+    if (!ctx->abricks) {
         vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
         return VRM_ERR_STATE;
     }
+    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx) && (rc = grid_expand(ctx))) return rc;
     REQUIRE(cameras != nullptr && rgba_f32_device != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
@@ -826,10 +901,11 @@ extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_unifor
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (!ctx->vox) {
+    if (!ctx->abricks) {
         vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
         return VRM_ERR_STATE;
     }
+    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx) && (rc = grid_expand(ctx))) return rc;
     REQUIRE(cameras != nullptr && out_total != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
@@ -986,7 +1062,8 @@ extern "C" int vrm_grid_broadcast(vrm_ctx *ctx, int root)
         return VRM_ERR_STATE;
     }
     REQUIRE(root >= 0 && root < ctx->comm_size, "root %d outside the %d ranks", root, ctx->comm_size);
-    REQUIRE(ctx->vox != nullptr && ctx->vox_words != 0, "no grid");
+    REQUIRE(ctx->abricks != nullptr && ctx->vox_words != 0, "no grid");
+    if ((rc = grid_expand(ctx))) return rc; // (what travels is the RGBA8 form every rank ingests)
     REQUIRE(ctx->gdim[2] == ctx->dim[2], "a slab-partitioned grid is not replicated: nothing to broadcast");
     // every rank must hold a grid of the same dimensions (vrm_grid_resize); the root's voxels replace the others' in place
     const int e = rccl().Broadcast(ctx->vox, ctx->vox, ctx->vox_words * 4, /* ncclUint8 */ 1, root, ctx->comm, ctx->stream);
@@ -1011,6 +1088,7 @@ extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
 {
     REQUIRE(ctx != nullptr, "null context");
     switch (option) {
+    case VRM_OPT_COMPACT_SCALAR: ctx->opt_compact = value; break;
     case VRM_OPT_KERNEL: ctx->opt_kernel = value; break;
     case VRM_OPT_SKIP_EMPTY: ctx->opt_skip = value; break;
     case VRM_OPT_PROFILE: ctx->opt_profile = value; break;
@@ -1032,6 +1110,7 @@ extern "C" int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value)
     case VRM_OPT_DIAGNOSTICS: *value = ctx->opt_diag; break;
     case VRM_OPT_CHUNK_STEPS: *value = ctx->opt_chunk; break;
     case VRM_OPT_PACKED_ALPHA: *value = ctx->opt_packed; break;
+    case VRM_OPT_COMPACT_SCALAR: *value = ctx->opt_compact; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;

@@ -23,7 +23,10 @@ struct VrmViewDesc {
 
 // Volume as the kernels see it.
 struct VrmGridDev {
-    const uint32_t *vox; // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211)
+    // RGBA8 words (r | g<<8 | b<<16 | a<<24), x fastest: idx = x + X*(y + Y*z)  (grid.rs:211).  nullptr (and `bricks` too) while a
+    // SCALAR volume is held in its compact form -- packed alpha bricks + occupancy pyramid, 1 B/voxel -- which is all the packed
+    // 1-channel march reads; the host re-expands before anything else needs them (vrm_api.cpp grid_expand)
+    const uint32_t *vox;
     uint32_t dim[3];
     uint32_t scalar;     // 1 => every voxel has r == g == b == a (DAT volumes, dat.rs:74)
     const uint8_t *occ;  // max alpha per 4x4x4-texel cell, x fastest (exact empty-space skipping): level 0 of a max pyramid
@@ -91,6 +94,8 @@ hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], u
 // bytes of the packed alpha bricks of a dim[0] x dim[1] x dim[2] volume, and their builder
 size_t vrm_alpha_bricks_bytes(const uint32_t dim[3]);
 hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream);
+// a scalar volume's x-fastest RGBA8 voxels ([b,b,b,b]) back from its packed alpha bricks
+hipError_t vrm_launch_expand_alpha_bricks(const uint32_t *abricks, const uint32_t dim[3], uint32_t *vox, hipStream_t stream);
 hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream);
 hipError_t vrm_launch_quantize_f32(const float *src_czyx, uint32_t channels, size_t n_voxels, uint32_t *dst, hipStream_t stream);
 hipError_t vrm_launch_quantize_scalar(const uint8_t *raw, uint32_t bytes_per_sample, size_t n_voxels, uint32_t *dst,

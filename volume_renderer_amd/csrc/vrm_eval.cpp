@@ -35,6 +35,7 @@ struct DevBuf { // freed on every return path
 int compare_volume(vrm_ctx *ctx, const float *data_dev, int density_only, float *out_rmse)
 {
     const size_t n = ctx->vox_words;
+    if (int rc_ = vrm_grid_expand_internal(ctx)) return rc_; // (the compare reads the x-fastest RGBA8 voxels)
     const uint32_t blocks = vrm_reduce_blocks(n);
     DevBuf partial;
     HIP_TRY(hipMalloc(&partial.p, blocks * sizeof(double)));

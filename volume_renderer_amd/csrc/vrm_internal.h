@@ -20,7 +20,7 @@ struct vrm_ctx {
     // and owns the samples of slices [slab_z0, slab_z1).  Unpartitioned: gdim == dim, z_store0 = 0, slab = [0, dim[2]).
     uint32_t gdim[3] = {0, 0, 0};
     uint32_t z_store0 = 0, slab_z0 = 0, slab_z1 = 0;
-    uint32_t *vox = nullptr; // RGBA8 words, x fastest
+    uint32_t *vox = nullptr; // RGBA8 words, x fastest (nullptr, like `bricks`, while a scalar volume is held compact: vrm_api.cpp grid_compact)
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere
     uint8_t *occ = nullptr;  // max alpha per 4x4x4-texel cell, rebuilt whenever the voxels change
@@ -47,7 +47,7 @@ struct vrm_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // options
-    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1;
+    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1, opt_compact = 1;
 
     // profiling (VRM_OPT_PROFILE)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -55,6 +55,9 @@ struct vrm_ctx {
     double prof_ms = 0.0;
     uint64_t prof_launches = 0;
 };
+
+// (vrm_api.cpp) a scalar volume held in its compact form gets its x-fastest RGBA8 copy and RGBA bricks back; no-op otherwise
+int vrm_grid_expand_internal(vrm_ctx *ctx);
 
 struct vrm_image {
     vrm_ctx *ctx = nullptr;      // nullptr once the context was destroyed: only vrm_image_destroy is valid then

@@ -329,6 +329,30 @@ __device__ __forceinline__ void fetch_global(const VrmGridDev &g, int ix, int iy
     c[6] = g.vox[r11 + x0]; c[7] = g.vox[r11 + x1];
 }
 
+// The packed alpha bricks by texel (VrmGridDev::abricks; x, y, z inside the volume): word index of the four texels
+// 4*xw .. 4*xw+3 of row (y, z), and one texel's alpha.  What the packed march reads where it cannot stage whole quads, so
+// that a scalar volume needs neither the x-fastest RGBA copy nor the RGBA bricks to be resident.
+__device__ __forceinline__ size_t abrick_word(const VrmGridDev &g, uint32_t xw, uint32_t y, uint32_t z)
+{
+    return ((((size_t)(z >> 1) * g.nby + (y >> 2)) * g.nbxa + (xw >> 2)) << 5) + ((z & 1u) << 4) + ((y & 3u) << 2) + (xw & 3u);
+}
+__device__ __forceinline__ uint32_t abrick_alpha(const VrmGridDev &g, uint32_t x, uint32_t y, uint32_t z)
+{
+    return (g.abricks[abrick_word(g, x >> 2, y, z)] >> (8u * (x & 3u))) & 0xffu;
+}
+// 8 corner texels of a scalar volume from the packed alpha bricks, as words with the alpha byte set (clamp-to-edge)
+__device__ __forceinline__ void fetch_global_alpha(const VrmGridDev &g, int ix, int iy, int iz, uint32_t c[8])
+{
+    const int mx = (int)g.dim[0] - 1, my = (int)g.dim[1] - 1, mz = (int)g.dim[2] - 1;
+    const uint32_t x0 = (uint32_t)min(max(ix, 0), mx), x1 = (uint32_t)max(min(ix + 1, mx), 0);
+    const uint32_t y0 = (uint32_t)min(max(iy, 0), my), y1 = (uint32_t)max(min(iy + 1, my), 0);
+    const uint32_t z0 = (uint32_t)min(max(iz, 0), mz), z1 = (uint32_t)max(min(iz + 1, mz), 0);
+    c[0] = abrick_alpha(g, x0, y0, z0) << 24; c[1] = abrick_alpha(g, x1, y0, z0) << 24;
+    c[2] = abrick_alpha(g, x0, y1, z0) << 24; c[3] = abrick_alpha(g, x1, y1, z0) << 24;
+    c[4] = abrick_alpha(g, x0, y0, z1) << 24; c[5] = abrick_alpha(g, x1, y0, z1) << 24;
+    c[6] = abrick_alpha(g, x0, y1, z1) << 24; c[7] = abrick_alpha(g, x1, y1, z1) << 24;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Variant 0: software trilinear straight from global memory.  One thread per pixel, one wave per
 // 8x8 pixel tile, 4 waves per workgroup.  Correctness baseline and A/B reference for variant 1.
@@ -1025,14 +1049,16 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                     const uint32_t gy = (uint32_t)min(max(ilo[1] + ey, 0), mxy);
                     const uint32_t gz = (uint32_t)min(max(ilo[2] + ez, 0), mxz);
                     if (lane_on) {
-                        const uint32_t *vrow = g.vox + ((size_t)gz * g.dim[1] + gy) * g.dim[0];
-                        uint32_t w = vrow[gx];
-                        if (PACKED) { // alpha of texels tx0 .. tx0+3, each clamped to the edge
-                            w >>= 24;
-#pragma unroll
-                            for (int k = 1; k < 4; ++k) w |= (vrow[min(max(tx0 + k, 0), mxx)] >> 24) << (8 * k);
+                        uint32_t w;
+                        if (PACKED) {
+                            // alpha of texels tx0 .. tx0+3, each clamped to the edge: a word that starts inside the padded brick
+                            // range is the stored word (texels past the volume repeat the edge there), a word outside it is
+                            // four copies of the edge texel -- from the packed bricks alone (a scalar volume keeps nothing else)
+                            if (tx0 >= 0 && tx0 < (int)(g.nbxa * 16u)) w = g.abricks[abrick_word(g, (uint32_t)tx0 >> 2, gy, gz)];
+                            else w = abrick_alpha(g, gx, gy, gz) * 0x01010101u;
                             seen |= w ? 0xff000000u : 0u;
                         } else {
+                            w = g.vox[((size_t)gz * g.dim[1] + gy) * g.dim[0] + gx];
                             seen |= w;
                         }
                         tile[ez * slice + ey * pitch + ex] = w;
@@ -1187,7 +1213,8 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                         const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
-                        fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+                        if (PACKED) fetch_global_alpha(g, (int)f0, (int)f1, (int)f2, c); // (the alpha byte is all the 1-channel filter reads)
+                        else fetch_global(g, (int)f0, (int)f1, (int)f2, c);
                         done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc);
                     }
                     // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
@@ -1448,6 +1475,19 @@ __global__ void __launch_bounds__(256) build_alpha_bricks_kernel(const uint32_t 
         u32x4 o;
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
         abricks[i] = o;
+    }
+}
+
+// The x-fastest RGBA8 voxels of a SCALAR volume back from its packed alpha bricks ([b,b,b,b], dat.rs:74): what a scalar
+// volume is expanded with when something needs the 4 B/voxel form again (download, broadcast, the RGBA-staged kernels).
+__global__ void __launch_bounds__(256) expand_alpha_bricks_kernel(const uint32_t *__restrict__ abricks, uint32_t X, uint32_t Y, uint32_t Z,
+                                                                  uint32_t nbxa, uint32_t nby, uint32_t *__restrict__ vox)
+{
+    const size_t n = (size_t)X * Y * Z, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t z = (uint32_t)(i / ((size_t)X * Y)), r = (uint32_t)(i - (size_t)z * X * Y), y = r / X, x = r - y * X;
+        const size_t w = ((((size_t)(z >> 1) * nby + (y >> 2)) * nbxa + (x >> 4)) << 5) + ((z & 1u) << 4) + ((y & 3u) << 2) + ((x >> 2) & 3u);
+        vox[i] = ((abricks[w] >> (8u * (x & 3u))) & 0xffu) * 0x01010101u;
     }
 }
 
@@ -1726,6 +1766,14 @@ hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim
     const size_t n_quads = (size_t)nbxa * nby * nbz * 8;
     hipLaunchKernelGGL(build_alpha_bricks_kernel, dim3(stream_blocks(n_quads)), dim3(256), 0, stream, vox, dim[0], dim[1], dim[2], nbxa,
                        nby, n_quads, reinterpret_cast<u32x4 *>(abricks));
+    return hipGetLastError();
+}
+
+hipError_t vrm_launch_expand_alpha_bricks(const uint32_t *abricks, const uint32_t dim[3], uint32_t *vox, hipStream_t stream)
+{
+    const uint32_t nbxa = (dim[0] + 15) / 16, nby = (dim[1] + 3) / 4;
+    hipLaunchKernelGGL(expand_alpha_bricks_kernel, dim3(stream_blocks((size_t)dim[0] * dim[1] * dim[2])), dim3(256), 0, stream, abricks, dim[0],
+                       dim[1], dim[2], nbxa, nby, vox);
     return hipGetLastError();
 }
 
