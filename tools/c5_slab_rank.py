@@ -44,17 +44,19 @@ def main():
     r.voxel_grid.upload_scalar(stored.reshape(-1), (dims[0], dims[1], s1 - s0), 1)
     r.synchronize()
     ingest_s = time.time() - t0
-    resident = free0 - torch.cuda.mem_get_info(0)[0] # the slab's device copies (RGBA8 texels, RGBA and packed-alpha bricks, occupancy pyramid)
+    resident = free0 - torch.cuda.mem_get_info(0)[0] # device memory the process took since before the context (the allocator may keep freed blocks)
+    grid_resident = r.voxel_grid.resident_bytes()     # what the grid holds: packed alpha bricks + pyramid for a scalar volume (compact form)
     print(f"slab {a.slab}/{a.slabs}: slices [{z0},{z1}) stored [{s0},{s1}), {stored.nbytes / 1e9:.2f} GB input, "
           f"generated in {gen_s:.1f} s, ingested in {ingest_s:.2f} s, nonzero {np.count_nonzero(stored) / stored.size:.3f}, "
-          f"{resident / 1e9:.2f} GB resident in HBM", flush=True)
+          f"grid holds {grid_resident / 1e9:.2f} GB ({grid_resident / stored.nbytes:.2f} x input), process took {resident / 1e9:.2f} GB of HBM", flush=True)
     views = oracle.sphere_views(8, 5)
     picks = [views[i] for i in np.linspace(0, len(views) - 1, a.views).astype(int)]
     cams36 = [oracle.camera_uniform(oracle.sphere_position(ix, iy, 8, 5, 2.5)) for ix, iy in picks]
     cams = [vr.uniform_from_array(c) for c in cams36]
     part = torch.empty((len(cams), R, R, 4), dtype=torch.float32, device="cuda:0")
     out = {"dims": dims, "slabs": a.slabs, "slab": a.slab, "res": R, "views": picks, "gen_s": gen_s, "ingest_s": ingest_s,
-           "stored_slices": [s0, s1], "input_bytes": int(stored.nbytes), "hbm_bytes_resident": int(resident)}
+           "stored_slices": [s0, s1], "input_bytes": int(stored.nbytes), "grid_bytes_resident": int(grid_resident),
+           "grid_resident_over_input": round(grid_resident / stored.nbytes, 3), "hbm_bytes_taken_by_process": int(resident)}
     res = {}
     for skip in (1, 0):
         r.set_option(vr.OPT_SKIP_EMPTY, skip)
