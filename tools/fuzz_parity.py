@@ -73,7 +73,8 @@ def main():
             continue                                    # look direction parallel to the up vector: degenerate basis
         cam = orc.camera_uniform(pos, target=tgt, aspect=W / H)
         opts = {vr.OPT_KERNEL: int(rng.choice([0, 1, 1, 1, 2, 2, 3, 4])), vr.OPT_SKIP_EMPTY: int(rng.integers(0, 2)),
-                vr.OPT_PACKED_ALPHA: int(rng.integers(0, 2)), vr.OPT_CHUNK_STEPS: int(rng.choice([0, 0, 1, 3, 40]))}
+                vr.OPT_PACKED_ALPHA: int(rng.integers(0, 2)), vr.OPT_CHUNK_STEPS: int(rng.choice([0, 0, 1, 3, 40])),
+                vr.OPT_COMPACT_SCALAR: int(rng.integers(0, 2))}
         for k, v in opts.items():
             rm.set_option(k, v)
         desc = f"case {case}: dims {dims} {kind} image {W}x{H} att {att} tf {tf} cam {mode} {np.round(pos, 3).tolist()} opts {list(opts.values())}"
@@ -87,7 +88,11 @@ def main():
                 # rays of 5000 steps through noise at attenuation 100 (5000-term blends in two association orders), and cameras
                 # thousands of texels away, short of the 4096 where the kernels switch to the oracle's coordinate sequence
                 # (FAR instance).  The 8-bit gates (<= 1 LSB, RMSE < 1e-3) are the contract and are never scaled.
-                check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=2.0)
+                # Only those two families get the wider gate: attenuation 100, or a camera more than 1000 texels from
+                # the volume's origin; every other case is held to the matrix's 1e-4.
+                far_texels = max(abs(float(p_)) for p_ in pos) * min(dims)   # the camera's distance in texels (the unit edge has min(dims) of them)
+                wide = att >= 100.0 or far_texels > 1000.0
+                check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=2.0 if wide else 1.0)
             else:
                 # the exact `alpha >= 1.0` exit can fire (attenuation >= 693): WHEN it fires depends on the last ulp of a
                 # continuous quantity, so iteration counts may differ by a step; image and accumulators must still agree
