@@ -500,3 +500,22 @@ def test_scalar_volume_is_held_compact_and_expands_on_demand(vr, orc):
     assert r.voxel_grid.resident_bytes() >= 9 * n
     full.close()
     r.close()
+
+
+def test_comm_broadcast_two_ranks(tmp_path):
+    """the receiver branch of vrm_grid_broadcast (ncclBroadcast into a fresh grid, then bricks / packed alpha /
+    pyramid / scalar detection of the received voxels) between two DIFFERENT GPUs, one process per GPU.  Skipped on a one-GPU
+    box (all this pool lends): there the multi-rank path stays unmeasured on hardware, as DESIGN.md section 5 says."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idf = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "rccl_broadcast_rank.py"), str(r), "2", idf, str(tmp_path / f"out{r}")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    h = [(tmp_path / f"out{r}").read_text() for r in range(2)]
+    assert h[0] == h[1] and len(h[0]) == 64                       # same voxels downloaded, same image rendered on both ranks
