@@ -21,6 +21,9 @@
 #ifndef VRM_CAP_PACKED
 #define VRM_CAP_PACKED VRM_CAP_DEFAULT /* LDS words per wave of the packed 1-channel march */
 #endif
+#ifndef VRM_INTERIOR_NO_CLAMP
+#define VRM_INTERIOR_NO_CLAMP 1 /* A/B: 0 keeps the LDS address clamp in interior chunks too */
+#endif
 #ifndef VRM_WEIGHTS_FIRST
 #define VRM_WEIGHTS_FIRST 0 /* A/B: trilinear filter of the RGBA march as eight corner weights + byte * weight products */
 #endif
@@ -1158,7 +1161,10 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                             // of slack); the clamp is insurance against a rounding surprise, the weights stay unclamped
                             // (PACKED: the tile's rows are byte-linear in x -- byte x - 4 * x0u of the row is texel x)
                             const float af = __builtin_fmaf(f2 - o2, fsl4, __builtin_fmaf(f1 - o1, fpx4, PACKED ? f0 + x04 : __builtin_fmaf(f0, 4.0f, x04))); // exact: small integers
-                            const int a0 = (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax4);
+                            // (interior chunks: every sample lies inside the volume and the box holds its cell by construction --
+                            // the geometric bound with its 0.01-texel slack -- so the clamp, one half-rate instruction per sample,
+                            // is left to the border chunks, where a sample rejected by the in-box test has no cell in the box)
+                            const int a0 = INTERIOR && VRM_INTERIOR_NO_CLAMP ? (int)af : (int)__builtin_amdgcn_fmed3f(af, 0.0f, amax4);
                             const int a1 = a0 + pitch4, a2 = a0 + slice4, a3 = a2 + pitch4;
                             if constexpr (PACKED) {
                                 // (written out: the compiler merges the byte pair of a row into one ds_read_u16, and a halfword read
