@@ -189,11 +189,18 @@ VRM_API int vrm_load_netcdf(vrm_ctx *ctx, const char *path);
 /* loaders::netcdf::write_voxel_grid (loaders/netcdf.rs:8-31): dimensions c=4,z,y,x and `color` = voxel/255.0 as f32,
  * written as a classic file (CDF-1 below 2 GiB, CDF-2 below 4 GiB, CDF-5 beyond). */
 VRM_API int vrm_write_netcdf(vrm_ctx *ctx, const char *path);
+/* The same volume in the container the reference's own writer makes (`netcdf::create`, netcdf.rs:10): NetCDF-4 = HDF5,
+ * in the oldest dialect of that format (superblock 0, symbol-table root group, contiguous little-endian `color`, the
+ * dimensions as dimension-scale datasets with netcdf-c's CLASS / NAME / _Netcdf4Dimid attributes, `color` with
+ * _Netcdf4Coordinates).  Parity unpinned: checked against this library's reader and a second restatement of the
+ * specification (tests/hdf5_builder.py), not against netcdf-c, which does not exist in the build environment. */
+VRM_API int vrm_write_netcdf4(vrm_ctx *ctx, const char *path);
 /* The container alone, host only (no context, no GPU): with color_czyx == NULL a size query that sets x, y, z;
  * otherwise 4*x*y*z floats in file order (c slowest, x fastest) converted to host byte order. */
 VRM_API int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *color_czyx,
                                   size_t capacity_floats);
 VRM_API int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);
+VRM_API int vrm_netcdf_write_color_nc4(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);
 
 /* ---- volume broadcast between the ranks of a view-partitioned export ---------------------
  * No reference counterpart (the reference is one process on one adapter).  north_star: "the volume is broadcast once

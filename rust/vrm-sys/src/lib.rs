@@ -80,8 +80,10 @@ extern "C" {
     // NetCDF interchange (loaders/netcdf.rs)
     pub fn vrm_load_netcdf(ctx: *mut vrm_ctx, path: *const c_char) -> c_int;
     pub fn vrm_write_netcdf(ctx: *mut vrm_ctx, path: *const c_char) -> c_int;
+    pub fn vrm_write_netcdf4(ctx: *mut vrm_ctx, path: *const c_char) -> c_int;
     pub fn vrm_netcdf_read_color(path: *const c_char, x: *mut u32, y: *mut u32, z: *mut u32, color_czyx: *mut f32, capacity_floats: usize) -> c_int;
     pub fn vrm_netcdf_write_color(path: *const c_char, x: u32, y: u32, z: u32, color_czyx: *const f32) -> c_int;
+    pub fn vrm_netcdf_write_color_nc4(path: *const c_char, x: u32, y: u32, z: u32, color_czyx: *const f32) -> c_int;
     // sort-last rendering of a z-slab-partitioned volume
     pub fn vrm_grid_resize_slab(ctx: *mut vrm_ctx, x: u32, y: u32, z: u32, z_begin: u32, z_end: u32) -> c_int;
     pub fn vrm_grid_resident_bytes(ctx: *mut vrm_ctx, bytes: *mut usize) -> c_int;

@@ -136,15 +136,26 @@ def msg_link_info():
     return struct.pack("<BBQQQQ", 0, 0x03, 4, UNDEF, UNDEF, UNDEF)   # creation order tracked + indexed, compact storage
 
 
-def msg_attribute_v1(name, text):
-    """A scalar fixed-length string attribute (the kind netcdf-c hangs on everything); the reader ignores attributes."""
-    nb, tb = name.encode() + b"\0", text.encode()
-    dt = struct.pack("<BBBBI", 0x13, 0, 0, 0, len(tb))          # class 3 (string), null-terminated ASCII
-    ds = struct.pack("<BBBB4x", 1, 0, 0, 0)                      # scalar dataspace, version 1
+def _attribute_v1(name, dt, ds, value):
+    nb = name.encode() + b"\0"
 
     def pad8(b):
         return b + b"\0" * (-len(b) % 8)
-    return struct.pack("<BxHHH", 1, len(nb), len(dt), len(ds)) + pad8(nb) + pad8(dt) + pad8(ds) + tb
+    return struct.pack("<BxHHH", 1, len(nb), len(dt), len(ds)) + pad8(nb) + pad8(dt) + pad8(ds) + value
+
+
+def msg_attribute_v1(name, text):
+    """A scalar fixed-length string attribute (the kind netcdf-c hangs on everything); the reader ignores attributes."""
+    tb = text.encode()
+    dt = struct.pack("<BBBBI", 0x13, 0, 0, 0, len(tb))          # class 3 (string), null-terminated ASCII
+    return _attribute_v1(name, dt, msg_dataspace_v1([]), tb)
+
+
+def msg_attribute_i32(name, values, scalar):
+    """A little-endian signed 32-bit attribute: a scalar or a vector (netcdf-c's _Netcdf4Dimid / _Netcdf4Coordinates)."""
+    dt = struct.pack("<BBBBI", 0x10, 0x08, 0, 0, 4) + struct.pack("<HH", 0, 32)   # class 0, signed; bit offset 0, precision 32
+    ds = msg_dataspace_v1([]) if scalar else msg_dataspace_v1([len(values)])
+    return _attribute_v1(name, dt, ds, b"".join(struct.pack("<i", v) for v in values))
 
 
 # ---- object headers -----------------------------------------------------------------------------------------------------
@@ -186,6 +197,55 @@ def dimension_scale_messages(n, v2):
     ds = msg_dataspace_v2([n]) if v2 else msg_dataspace_v1([n])
     return [(0x01, ds), (0x03, msg_datatype_f32(True)), (0x08, msg_layout_contiguous(UNDEF, 0)),
             (0x0C, msg_attribute_v1("CLASS", "DIMENSION_SCALE\0"))]
+
+
+def netcdf4_classic_model(color):
+    """The file csrc/vrm_hdf5.cpp's writer (vrm_netcdf_write_color_nc4) makes for color(4, Z, Y, X), assembled here
+    independently: the `old_style` dialect with netcdf-c's attributes (CLASS, NAME, _Netcdf4Dimid on the dimension scales,
+    _Netcdf4Coordinates on the variable), full-size symbol and B-tree nodes, and the root entry's scratch filled in."""
+    color = np.ascontiguousarray(color, dtype="<f4")
+    _, Z, Y, X = color.shape
+    img = Image()
+    sb = img.alloc(96)
+    data_addr = img.append(color.tobytes())
+    fill = (0x05, struct.pack("<BBBB", 2, 2, 2, 0))
+
+    def scale(i, n):
+        name = "This is a netCDF dimension but not a netCDF variable.%10d" % n
+        return object_header_v1(img, [(0x01, msg_dataspace_v1([n])), (0x03, msg_datatype_f32(True)), fill,
+                                      (0x08, msg_layout_contiguous(UNDEF, 4 * n)), (0x0C, msg_attribute_v1("CLASS", "DIMENSION_SCALE\0")),
+                                      (0x0C, msg_attribute_v1("NAME", name + "\0")), (0x0C, msg_attribute_i32("_Netcdf4Dimid", [i], True))])
+    objs = {"c": scale(0, 4), "z": scale(1, Z), "y": scale(2, Y), "x": scale(3, X)}
+    objs["color"] = object_header_v1(img, [(0x01, msg_dataspace_v1(color.shape)), (0x03, msg_datatype_f32(False)), fill,
+                                           (0x08, msg_layout_contiguous(data_addr, color.nbytes)),
+                                           (0x0C, msg_attribute_i32("_Netcdf4Coordinates", [0, 1, 2, 3], False))])
+    names = sorted(objs)
+    heap_data = bytearray(b"\0" * 8)
+    name_off = {}
+    for n in names:
+        name_off[n] = len(heap_data)
+        heap_data += n.encode() + b"\0"
+        heap_data += b"\0" * (-len(heap_data) % 8)
+    heap_data_addr = img.append(bytes(heap_data))
+    heap = img.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, heap_data_addr))
+    leaf_k, internal_k = 4, 16
+    snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
+    for n in names:
+        snod += struct.pack("<QQII16x", name_off[n], objs[n], 0, 0)
+    snod += b"\0" * (40 * (2 * leaf_k - len(names)))
+    snod_addr = img.append(snod)
+    tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, name_off[names[-1]])
+    tree += b"\0" * (16 * (2 * internal_k - 1))
+    tree_addr = img.append(tree)
+    root = object_header_v1(img, [(0x11, msg_symbol_table(tree_addr, heap)),
+                                  (0x0C, msg_attribute_v1("_NCProperties", "version=2,volume_renderer_amd=3\0"))])
+    eof = len(img.b)
+    sblock = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0) + struct.pack("<HHI", leaf_k, internal_k, 0)
+    sblock += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    sblock += struct.pack("<QQIIQQ", 0, root, 1, 0, tree_addr, heap)
+    assert len(sblock) == 96
+    img.put(sb, sblock)
+    return bytes(img.b)
 
 
 def old_style(color, dims_extra=None):

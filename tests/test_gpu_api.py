@@ -268,6 +268,12 @@ def test_netcdf_load_and_write(rm1, vr, orc, tmp_path):
     fr.close()
     rm1.load_netcdf(out)                                                            # write -> load is the identity on the voxels
     assert np.array_equal(g.download_rgba8(), vox)
+    out4 = os.path.join(tmp_path, "out4.nc")                                         # the container netcdf::create itself makes (HDF5)
+    rm1.write_netcdf(out4, format="netcdf4")
+    assert open(out4, "rb").read(4) == b"\x89HDF" and np.array_equal(netcdf.read_color(out4), want)
+    g.new((3, 3, 3))
+    rm1.load_netcdf(out4)
+    assert g.dimensions == (11, 9, 7) and np.array_equal(g.download_rgba8(), vox)
     with pytest.raises(vr.VrmError):
         rm1.load_netcdf(os.path.join(tmp_path, "missing.nc"))
 

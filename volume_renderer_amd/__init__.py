@@ -389,9 +389,13 @@ class RayMarcher:
         self.voxel_grid.attenuation = 1.0
         self.voxel_grid.transfer_function_colors = VoxelGrid._default_tf()
 
-    def write_netcdf(self, path):
-        """loaders::netcdf::write_voxel_grid (netcdf.rs:8-31)."""
-        _ffi.check(_ffi.lib().vrm_write_netcdf(self._h, os.fsencode(path)))
+    def write_netcdf(self, path, format="classic"):
+        """loaders::netcdf::write_voxel_grid (netcdf.rs:8-31); `format` "classic" (CDF-1/2/5) or "netcdf4" (the HDF5 container
+        the reference's `netcdf::create` makes)."""
+        if format not in ("classic", "netcdf4"):
+            raise ValueError(f"format is 'classic' or 'netcdf4', got {format!r}")
+        fn = _ffi.lib().vrm_write_netcdf if format == "classic" else _ffi.lib().vrm_write_netcdf4
+        _ffi.check(fn(self._h, os.fsencode(path)))
 
     def compare_to_netcdf_rmse(self, color_czyx, density_only):
         """compare::netcdf::compare_to_netcdf_rmse (compare/netcdf.rs:8-75) against an in-memory `color(c,z,y,x)` f32 array."""

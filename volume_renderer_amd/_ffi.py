@@ -98,8 +98,10 @@ SYMBOLS = {
     "vrm_comm_destroy": (ctypes.c_int, [_vp]),
     "vrm_load_netcdf": (ctypes.c_int, [_vp, ctypes.c_char_p]),
     "vrm_write_netcdf": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    "vrm_write_netcdf4": (ctypes.c_int, [_vp, ctypes.c_char_p]),
     "vrm_netcdf_read_color": (ctypes.c_int, [ctypes.c_char_p, _u32p, _u32p, _u32p, _vp, ctypes.c_size_t]),
     "vrm_netcdf_write_color": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
+    "vrm_netcdf_write_color_nc4": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]),
     "vrm_grid_resize_slab": (ctypes.c_int, [_vp] + [ctypes.c_uint32] * 5),
     "vrm_grid_get_slab": (ctypes.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
     "vrm_grid_resident_bytes": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t)]),

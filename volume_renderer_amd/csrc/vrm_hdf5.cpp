@@ -567,3 +567,187 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
         return VRM_ERR_IO;
     }
 }
+
+// ---- writer --------------------------------------------------------------------------------------------------------
+// loaders::netcdf::write_voxel_grid (loaders/netcdf.rs:8-31) creates its file with `netcdf::create`, i.e. a NetCDF-4 /
+// HDF5 container.  This writes that container in the oldest dialect every HDF5 library reads (the one netcdf-c itself
+// produced before 4.x turned creation-order tracking on): superblock version 0, version-1 object headers, the root group
+// as a symbol table (one B-tree node, one symbol node, a local heap), `color(c,z,y,x)` a contiguous little-endian f32
+// dataset, and the four dimensions c, z, y, x as dimension-scale datasets without storage that carry netcdf-c's
+// attributes (CLASS, NAME, _Netcdf4Dimid); `color` carries _Netcdf4Coordinates = {0,1,2,3}, the attribute netcdf-c
+// reads the dimension ids of a variable from, so no object references (DIMENSION_LIST / REFERENCE_LIST) are written.
+// PARITY UNPINNED, like the reader above: no HDF5 / netCDF library exists here to open the result with.  The tests pin it
+// two ways: the reader above reads it back bit for bit, and tests/hdf5_builder.py, a second restatement of the same
+// specification in another language, assembles the same file byte for byte.
+namespace {
+
+struct Bytes {
+    std::vector<uint8_t> b;
+    void u(uint64_t v, int n) { for (int i = 0; i < n; ++i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void raw(const void *p, size_t n) { const uint8_t *q = static_cast<const uint8_t *>(p); b.insert(b.end(), q, q + n); }
+    void zeros(size_t n) { b.insert(b.end(), n, 0); }
+    void pad8() { zeros((8 - b.size() % 8) % 8); }
+    void cat(const Bytes &o) { b.insert(b.end(), o.b.begin(), o.b.end()); }
+};
+
+typedef std::pair<int, Bytes> Msg; // (message type, body)
+
+Bytes dataspace_v1(const std::vector<uint64_t> &dims)
+{
+    Bytes m;
+    m.u(1, 1); m.u(dims.size(), 1); m.u(0, 1); m.u(0, 1); m.zeros(4);
+    for (uint64_t d : dims) m.u(d, 8);
+    return m;
+}
+Bytes datatype_f32(bool big_endian)
+{
+    Bytes m; // class 1 version 1; byte order, mantissa normalisation 2 (implied msb); sign bit 31; 4 bytes
+    m.u(0x11, 1); m.u((big_endian ? 1 : 0) | (2 << 4), 1); m.u(31, 1); m.u(0, 1); m.u(4, 4);
+    m.u(0, 2); m.u(32, 2); m.u(23, 1); m.u(8, 1); m.u(0, 1); m.u(23, 1); m.u(127, 4); // bit offset, precision, exponent at 23 (8 bits), mantissa at 0 (23 bits), bias
+    return m;
+}
+Bytes datatype_i32()
+{
+    Bytes m; // class 0 version 1; little-endian, signed
+    m.u(0x10, 1); m.u(0x08, 1); m.u(0, 1); m.u(0, 1); m.u(4, 4); m.u(0, 2); m.u(32, 2);
+    return m;
+}
+Bytes datatype_string(size_t n)
+{
+    Bytes m; // class 3 version 1; null-terminated ASCII of n bytes
+    m.u(0x13, 1); m.u(0, 1); m.u(0, 1); m.u(0, 1); m.u(n, 4);
+    return m;
+}
+Bytes layout_contiguous(uint64_t addr, uint64_t size)
+{
+    Bytes m;
+    m.u(3, 1); m.u(1, 1); m.u(addr, 8); m.u(size, 8);
+    return m;
+}
+Bytes fill_value_undefined()
+{
+    Bytes m; // version 2, space allocated late, fill written if set, no fill value defined
+    m.u(2, 1); m.u(2, 1); m.u(2, 1); m.u(0, 1);
+    return m;
+}
+Bytes attribute_v1(const char *name, Bytes type, Bytes space, const Bytes &value)
+{
+    const size_t nn = strlen(name) + 1;
+    Bytes m;
+    m.u(1, 1); m.u(0, 1); m.u(nn, 2); m.u(type.b.size(), 2); m.u(space.b.size(), 2);
+    m.raw(name, nn); m.pad8();
+    type.pad8(); m.cat(type);
+    space.pad8(); m.cat(space);
+    m.cat(value);
+    return m;
+}
+Bytes attribute_string(const char *name, const std::string &text)
+{
+    Bytes v;
+    v.raw(text.c_str(), text.size() + 1); // the terminator belongs to the value
+    return attribute_v1(name, datatype_string(text.size() + 1), dataspace_v1({}), v);
+}
+Bytes attribute_i32(const char *name, const std::vector<int32_t> &values, bool scalar)
+{
+    Bytes v;
+    for (int32_t x : values) v.u((uint32_t)x, 4);
+    return attribute_v1(name, datatype_i32(), scalar ? dataspace_v1({}) : dataspace_v1({values.size()}), v);
+}
+
+// appends a version-1 object header, returns its offset in `img`
+size_t object_header_v1(Bytes &img, const std::vector<Msg> &msgs)
+{
+    Bytes body;
+    for (const Msg &m : msgs) {
+        Bytes d = m.second;
+        d.pad8();
+        body.u((uint64_t)m.first, 2); body.u(d.b.size(), 2); body.u(0, 1); body.zeros(3);
+        body.cat(d);
+    }
+    img.pad8();
+    const size_t at = img.b.size();
+    img.u(1, 1); img.u(0, 1); img.u(msgs.size(), 2); img.u(1, 4); img.u(body.b.size(), 4); img.zeros(4);
+    img.cat(body);
+    return at;
+}
+
+const int GROUP_LEAF_K = 4, GROUP_INTERNAL_K = 16;
+
+} // namespace
+
+int vrm_hdf5_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx)
+{
+    static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+    const uint64_t n = (uint64_t)4 * x * y * z, bytes = n * 4;
+    const uint64_t data_addr = 96;         // right behind the superblock
+    const uint64_t base = data_addr + bytes; // metadata behind the data (a multiple of 8)
+    Bytes img;
+    const char *all[5] = {"c", "z", "y", "x", "color"}; // netcdf.rs:11-16
+    const uint64_t lens[4] = {4, z, y, x};
+    uint64_t obj[5];
+    for (int i = 0; i < 4; ++i) {
+        char text[80];
+        snprintf(text, sizeof text, "This is a netCDF dimension but not a netCDF variable.%10llu", (unsigned long long)lens[i]);
+        obj[i] = base + object_header_v1(img, {{0x01, dataspace_v1({lens[i]})}, {0x03, datatype_f32(true)}, {0x05, fill_value_undefined()},
+                                               {0x08, layout_contiguous(UNDEF, lens[i] * 4)}, {0x0C, attribute_string("CLASS", "DIMENSION_SCALE")},
+                                               {0x0C, attribute_string("NAME", text)}, {0x0C, attribute_i32("_Netcdf4Dimid", {i}, true)}});
+    }
+    obj[4] = base + object_header_v1(img, {{0x01, dataspace_v1({4, z, y, x})}, {0x03, datatype_f32(false)}, {0x05, fill_value_undefined()}, // netcdf.rs:16
+                                           {0x08, layout_contiguous(data_addr, bytes)}, {0x0C, attribute_i32("_Netcdf4Coordinates", {0, 1, 2, 3}, false)}});
+    // the root group's symbol table: entries sorted by name
+    const int order[5] = {0, 4, 3, 2, 1}; // "c" < "color" < "x" < "y" < "z"
+    Bytes heap; // offset 0: the empty name of the B-tree's first key
+    heap.zeros(8);
+    uint64_t name_off[5];
+    for (int k = 0; k < 5; ++k) {
+        name_off[order[k]] = heap.b.size();
+        heap.raw(all[order[k]], strlen(all[order[k]]) + 1);
+        heap.pad8();
+    }
+    img.pad8();
+    const uint64_t heap_data = base + img.b.size();
+    img.cat(heap);
+    img.pad8();
+    const uint64_t heap_addr = base + img.b.size();
+    img.raw("HEAP", 4); img.u(0, 1); img.zeros(3); img.u(heap.b.size(), 8); img.u(UNDEF, 8); img.u(heap_data, 8);
+    img.pad8();
+    const uint64_t snod = base + img.b.size();
+    img.raw("SNOD", 4); img.u(1, 1); img.u(0, 1); img.u(5, 2);
+    for (int k = 0; k < 5; ++k) { img.u(name_off[order[k]], 8); img.u(obj[order[k]], 8); img.u(0, 4); img.u(0, 4); img.zeros(16); }
+    img.zeros((size_t)(2 * GROUP_LEAF_K - 5) * 40); // a symbol node always has room for 2K entries
+    const uint64_t tree = base + img.b.size();
+    img.raw("TREE", 4); img.u(0, 1); img.u(0, 1); img.u(1, 2); img.u(UNDEF, 8); img.u(UNDEF, 8);
+    img.u(0, 8); img.u(snod, 8); img.u(name_off[order[4]], 8);
+    img.zeros((size_t)(2 * GROUP_INTERNAL_K - 1) * 16); // ... and a B-tree node for 2K children and 2K+1 keys
+    const uint64_t root = base + object_header_v1(img, {{0x11, [&] { Bytes m; m.u(tree, 8); m.u(heap_addr, 8); return m; }()},
+                                                        {0x0C, attribute_string("_NCProperties", "version=2,volume_renderer_amd=3")}});
+    const uint64_t eof = base + img.b.size();
+    Bytes sb;
+    sb.raw(sig, 8);
+    sb.u(0, 1); sb.u(0, 1); sb.u(0, 1); sb.u(0, 1); sb.u(0, 1); sb.u(8, 1); sb.u(8, 1); sb.u(0, 1); // versions; offsets and lengths of 8 bytes
+    sb.u(GROUP_LEAF_K, 2); sb.u(GROUP_INTERNAL_K, 2); sb.u(0, 4);
+    sb.u(0, 8); sb.u(UNDEF, 8); sb.u(eof, 8); sb.u(UNDEF, 8); // base, free-space info, end of file, driver info
+    sb.u(0, 8); sb.u(root, 8); sb.u(1, 4); sb.u(0, 4); sb.u(tree, 8); sb.u(heap_addr, 8); // root entry, its scratch = B-tree and heap
+    if (sb.b.size() != data_addr) {
+        vrm_set_error("internal: superblock of %zu bytes", sb.b.size());
+        return VRM_ERR_STATE;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        vrm_set_error("cannot create %s", path);
+        return VRM_ERR_IO;
+    }
+    bool ok = fwrite(sb.b.data(), 1, sb.b.size(), f) == sb.b.size();
+    const size_t step = (size_t)1 << 24;
+    for (uint64_t done = 0; ok && done < n; done += step) { // host floats are little-endian: stored as they are
+        const size_t k = (size_t)std::min<uint64_t>(step, n - done);
+        ok = fwrite(color_czyx + done, 4, k, f) == k;
+    }
+    ok = ok && fwrite(img.b.data(), 1, img.b.size(), f) == img.b.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        vrm_set_error("%s: write failed", path);
+        return VRM_ERR_IO;
+    }
+    return VRM_OK;
+}

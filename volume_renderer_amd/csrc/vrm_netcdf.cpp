@@ -20,6 +20,7 @@
 
 // vrm_hdf5.cpp: `color(c,z,y,x)` from a NetCDF-4 / HDF5 container
 int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *out, size_t capacity_floats);
+int vrm_hdf5_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);
 
 #define REQUIRE_IO(cond, ...)                             \
     do {                                                  \
@@ -293,10 +294,21 @@ extern "C" int vrm_load_netcdf(vrm_ctx *ctx, const char *path)
     });
 }
 
-// loaders::netcdf::write_voxel_grid (netcdf.rs:8-31)
-extern "C" int vrm_write_netcdf(vrm_ctx *ctx, const char *path)
+// The NetCDF-4 (HDF5) container, what the reference's `netcdf::create` (netcdf.rs:10) makes: csrc/vrm_hdf5.cpp
+extern "C" int vrm_netcdf_write_color_nc4(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx)
 {
-    return vrm_guard("vrm_write_netcdf", VRM_ERR_IO, [&]() -> int {
+    return vrm_guard("vrm_netcdf_write_color_nc4", VRM_ERR_IO, [&]() -> int {
+    if (!path || !color_czyx || x == 0 || y == 0 || z == 0) {
+        vrm_set_error("null argument or empty volume");
+        return VRM_ERR_INVALID;
+    }
+    return vrm_hdf5_write_color(path, x, y, z, color_czyx);
+    });
+}
+
+// loaders::netcdf::write_voxel_grid (netcdf.rs:8-31)
+static int write_voxel_grid(vrm_ctx *ctx, const char *path, bool nc4)
+{
     if (!ctx) {
         vrm_set_error("null context");
         return VRM_ERR_INVALID;
@@ -312,6 +324,16 @@ extern "C" int vrm_write_netcdf(vrm_ctx *ctx, const char *path)
     std::vector<float> data(n * 4);
     for (size_t i = 0; i < n; ++i)
         for (int c = 0; c < 4; ++c) data[(size_t)c * n + i] = (float)vox[4 * i + c] / 255.0f; // netcdf.rs:23
-    return vrm_netcdf_write_color(path, ctx->dim[0], ctx->dim[1], ctx->dim[2], data.data());
-    });
+    return nc4 ? vrm_netcdf_write_color_nc4(path, ctx->dim[0], ctx->dim[1], ctx->dim[2], data.data())
+               : vrm_netcdf_write_color(path, ctx->dim[0], ctx->dim[1], ctx->dim[2], data.data());
+}
+
+extern "C" int vrm_write_netcdf(vrm_ctx *ctx, const char *path)
+{
+    return vrm_guard("vrm_write_netcdf", VRM_ERR_IO, [&]() -> int { return write_voxel_grid(ctx, path, false); });
+}
+
+extern "C" int vrm_write_netcdf4(vrm_ctx *ctx, const char *path)
+{
+    return vrm_guard("vrm_write_netcdf4", VRM_ERR_IO, [&]() -> int { return write_voxel_grid(ctx, path, true); });
 }
