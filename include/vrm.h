@@ -300,11 +300,15 @@ typedef enum vrm_option {
     VRM_OPT_PACKED_ALPHA = 5, /* 1-channel march (scalar volumes, transfer function) staged from the packed alpha copy of
                                  the volume, one byte per texel: 1 = on (default), 0 = stage the RGBA8 texels instead (tuning; same
                                  image to f32 rounding) */
-    VRM_OPT_COMPACT_SCALAR = 6 /* default 1: after an upload that turned out scalar (r == g == b == a in every voxel: DAT files,
+    VRM_OPT_COMPACT_SCALAR = 6, /* default 1: after an upload that turned out scalar (r == g == b == a in every voxel: DAT files,
                                  1-channel f32) keep only what the 1-channel march reads -- packed alpha bricks + occupancy pyramid,
                                  about 1 B/voxel -- and release the 8 B/voxel of RGBA8 copies; they are rebuilt (exactly) when a
                                  download, a broadcast, the voxel compare or an RGBA-staging kernel option needs them.  0: keep
                                  everything resident (9 B/voxel).  Takes effect at the next upload. */
+    VRM_OPT_RAYS_PER_LANE = 7  /* wave tile of the packed scalar march: 0 (default) = automatic -- two rays per lane (16x8-pixel
+                                 tiles, one staged box per chunk shared by both rays) for volumes of more than 2^28 voxels when a
+                                 pixel is narrower than 0.6 texel in every view of the batch, else one (8x8) --, 1 / 2 = forced (tuning; the image does not
+                                 depend on it).  Far views, slab-partitioned volumes and the transfer function keep one. */
 } vrm_option;
 VRM_API int vrm_set_option(vrm_ctx *ctx, int option, int64_t value);
 VRM_API int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value);

@@ -43,6 +43,7 @@ pub const VRM_OPT_DIAGNOSTICS: c_int = 3;
 pub const VRM_OPT_CHUNK_STEPS: c_int = 4;
 pub const VRM_OPT_PACKED_ALPHA: c_int = 5;
 pub const VRM_OPT_COMPACT_SCALAR: c_int = 6;
+pub const VRM_OPT_RAYS_PER_LANE: c_int = 7;
 
 extern "C" {
     // RayMarcher (ray_marcher/mod.rs:18-142)

@@ -117,6 +117,23 @@ def test_rust_sys_crate_declares_every_symbol():
     assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
 
 
+def test_option_and_status_constants_agree_across_bindings():
+    """include/vrm.h, the ctypes mirror and the Rust FFI crate must name the same VRM_OPT_* / VRM_ERR_* values."""
+    import re
+    from conftest import ROOT
+    from volume_renderer_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "vrm.h")).read()
+    rust = open(os.path.join(ROOT, "rust", "vrm-sys", "src", "lib.rs")).read()
+    in_header = {k: int(v) for k, v in re.findall(r"\b(VRM_(?:OPT|ERR)_\w+|VRM_OK)\s*=\s*(-?\d+)", header)}
+    in_rust = {k: int(v) for k, v in re.findall(r"pub const (VRM_\w+): c_int = (-?\d+);", rust)}
+    opts = {k: v for k, v in in_header.items() if k.startswith("VRM_OPT_")}
+    assert len(opts) >= 8 and sorted(opts.values()) == list(range(len(opts)))
+    for k, v in in_header.items():
+        assert in_rust.get(k) == v, (k, v, in_rust.get(k))
+        py = k[4:] if k.startswith("VRM_OPT_") else k
+        assert getattr(_ffi, py) == v, (k, v)
+
+
 def test_rust_patch_keeps_reference_signatures():
     """rust/patch (f-3) cannot be compiled here; what can be checked is textual: the replacement files declare the public
     interface State calls with the reference's own signatures (ray_marcher/mod.rs:22,26,113; voxel/grid.rs:44,202,214,240,244),

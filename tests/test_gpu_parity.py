@@ -403,3 +403,46 @@ def test_executed_sample_counts(rm, vr, orc):
     assert (ex1 <= in1).all() and it0.max() < 5001
     if rm.get_option(vr.OPT_KERNEL) != 0:          # the global-gather baseline does not skip
         assert ex1.sum() < 0.9 * in1.sum()
+
+
+def test_two_rays_per_lane_against_oracle_and_one_ray_form(rm, vr, orc):
+    """VRM_OPT_RAYS_PER_LANE = 2: wave tiles of 16x8 pixels, each lane marches two x-adjacent pixels through one staged box per
+    chunk (the packed scalar march).  Against the oracle like every other form, and BIT-identical to the one-ray form in the
+    8-bit image, the f32 accumulators, the iteration counts and the ray geometry: how the march is cut into chunks does not
+    change what a sample contributes.  Image widths off the 16-pixel tile, a one-column image, dims off the brick grid, a
+    camera inside the volume, early termination, skipping on and off, both dispatch modes."""
+    cases = [((37, 21, 19), 6.0, 72, 56, 2.5), ((64, 64, 64), 3.0, 333, 90, 2.5), ((65, 3, 3), 30.0, 50, 37, 30.0), ((1, 1, 1), 80.0, 24, 24, 3.0),
+             ((50, 7, 33), 12.0, 1, 40, 9.0), ((40, 40, 40), 900.0, 130, 100, 2.5), ((96, 80, 112), 2.0, 256, 200, 1.6)]
+    try:
+        for dims, att, W, H, radius in cases:
+            sc = synth.blobs_scalar_u8(dims) if min(dims) >= 8 else np.random.default_rng(sum(dims)).integers(0, 256, dims[::-1], dtype=np.uint8)
+            vox = np.repeat(np.ascontiguousarray(sc)[..., None], 4, 3)
+            configure(rm, vox, att, False)
+            cams = [sphere_cam(orc, 1, 3, radius=radius, aspect=W / H), sphere_cam(orc, 6, 5, radius=radius, aspect=W / H),
+                    orc.camera_uniform((0.1, 0.05, -0.2), target=(0.4, 0.3, 0.5), aspect=W / H)]
+            for cam in cams:
+                for skip, kernel in [(1, 1), (0, 3), (1, 4)]:
+                    rm.set_option(vr.OPT_SKIP_EMPTY, skip)
+                    rm.set_option(vr.OPT_KERNEL, kernel)
+                    out = {}
+                    for rays in (1, 2):
+                        rm.set_option(vr.OPT_RAYS_PER_LANE, rays)
+                        out[rays] = draw(rm, vr, cam, W, H)
+                        part = torch.empty((1, H, W, 4), dtype=torch.float32, device="cuda")
+                        rm.draw_partial([vr.uniform_from_array(cam)], W, H, part.data_ptr())
+                        rm.synchronize()
+                        out[rays]["partial"] = part.cpu().numpy()[0]
+                    for k in ("rgba8", "f32", "iters", "geo", "partial"):
+                        a, b = np.ascontiguousarray(out[1][k]), np.ascontiguousarray(out[2][k])
+                        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (dims, W, H, skip, kernel, k)
+                    assert np.array_equal(out[2]["partial"].view(np.uint32), out[2]["f32"].view(np.uint32))
+                if att < 600.0:
+                    check(orc, out[2], vox, cam, W, H, att, False)
+                else:   # (early termination: the last step may round to 1.0 one iteration apart, see test_early_termination_matches_oracle)
+                    ref = orc.render(vox, cam, W, H, attenuation=att, want_steps=True)
+                    assert image_metrics(out[2]["rgba8"], ref["rgba8"])["max"] <= 1
+                    assert np.abs(out[2]["iters"].astype(int) - ref["steps"].astype(int)).max() <= 1
+    finally:
+        rm.set_option(vr.OPT_RAYS_PER_LANE, 0)
+        rm.set_option(vr.OPT_SKIP_EMPTY, 1)
+        rm.set_option(vr.OPT_KERNEL, 1)

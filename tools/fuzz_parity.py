@@ -74,7 +74,7 @@ def main():
         cam = orc.camera_uniform(pos, target=tgt, aspect=W / H)
         opts = {vr.OPT_KERNEL: int(rng.choice([0, 1, 1, 1, 2, 2, 3, 4])), vr.OPT_SKIP_EMPTY: int(rng.integers(0, 2)),
                 vr.OPT_PACKED_ALPHA: int(rng.integers(0, 2)), vr.OPT_CHUNK_STEPS: int(rng.choice([0, 0, 1, 3, 40])),
-                vr.OPT_COMPACT_SCALAR: int(rng.integers(0, 2))}
+                vr.OPT_COMPACT_SCALAR: int(rng.integers(0, 2)), vr.OPT_RAYS_PER_LANE: int(rng.choice([0, 1, 2, 2]))}
         for k, v in opts.items():
             rm.set_option(k, v)
         desc = f"case {case}: dims {dims} {kind} image {W}x{H} att {att} tf {tf} cam {mode} {np.round(pos, 3).tolist()} opts {list(opts.values())}"
@@ -114,6 +114,7 @@ def main():
     for k in (vr.OPT_KERNEL, vr.OPT_SKIP_EMPTY, vr.OPT_PACKED_ALPHA):
         rm.set_option(k, 1)
     rm.set_option(vr.OPT_CHUNK_STEPS, 0)
+    rm.set_option(vr.OPT_RAYS_PER_LANE, 0)
     for case in range(a.slab_cases):
         dims = (int(rng.integers(4, 40)), int(rng.integers(4, 40)), int(rng.integers(6, 70)))
         X, Y, Z = dims

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--att", type=float, default=1.0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--packed", type=int, default=1, help="VRM_OPT_PACKED_ALPHA")
+    ap.add_argument("--rays", type=int, default=0, help="VRM_OPT_RAYS_PER_LANE (0 = automatic)")
     ap.add_argument("--xdiv", type=int, default=16)
     ap.add_argument("--ydiv", type=int, default=17)
     ap.add_argument("--ix", type=int, default=-1, help="only the views of this azimuth index")
@@ -40,6 +41,7 @@ def main():
     rm.set_option(vr.OPT_SKIP_EMPTY, a.skip)
     rm.set_option(vr.OPT_CHUNK_STEPS, a.chunk)
     rm.set_option(vr.OPT_PACKED_ALPHA, a.packed)
+    rm.set_option(vr.OPT_RAYS_PER_LANE, a.rays)
     if a.scalar:
         s = synth.blobs_scalar_u8((D, D, D))
         rm.voxel_grid.upload_scalar(s.reshape(-1), (D, D, D), 1)

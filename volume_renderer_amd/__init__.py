@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import (CameraUniform, GridUniform, TransferFunction, VrmError, OPT_CHUNK_STEPS, OPT_DIAGNOSTICS, OPT_KERNEL,
-                   OPT_COMPACT_SCALAR, OPT_PACKED_ALPHA, OPT_PROFILE, OPT_SKIP_EMPTY)
+                   OPT_COMPACT_SCALAR, OPT_PACKED_ALPHA, OPT_PROFILE, OPT_RAYS_PER_LANE, OPT_SKIP_EMPTY)
 
 __all__ = ["RayMarcher", "VoxelGrid", "Screenshotter", "Camera", "CameraSphereController", "SphereScreenshotManager",
            "CameraUniform", "TransferFunction", "GridUniform", "VrmError", "sphere_views"]

@@ -20,6 +20,7 @@ OPT_DIAGNOSTICS = 3
 OPT_CHUNK_STEPS = 4
 OPT_PACKED_ALPHA = 5
 OPT_COMPACT_SCALAR = 6
+OPT_RAYS_PER_LANE = 7
 
 
 class VrmError(RuntimeError):

@@ -721,6 +721,44 @@ static uint32_t any_far_view(const VrmMarchParams &p, const vrm_camera_uniform *
     return 0u;
 }
 
+// rays per lane of the packed scalar march (VRM_OPT_RAYS_PER_LANE): two for volumes larger than the Infinity Cache where, in every
+// view of the batch, a pixel is narrower than 0.6 texel at the volume's centre -- the width of a pixel taken from the directions of two x-adjacent rays at the image
+// centre, by fs_main's own formula (wgsl:98-108).  The launcher drops to one for far or slab-partitioned views.
+static uint32_t rays_for_batch(const vrm_ctx *ctx, const VrmMarchParams &p, const vrm_camera_uniform *cameras, uint32_t n)
+{
+    if (ctx->opt_rays == 1 || ctx->opt_rays == 2) return (uint32_t)ctx->opt_rays;
+    // Measured (profiles/r3/rays_per_lane.txt): -9.5 % for a 1024^3 volume at 4096^2, nothing for 512^3 and 256^3 at 2048^2
+    // (what two rays save is staging traffic and prologues; a volume that sits in the 256 MB Infinity Cache is bound by its
+    // step loops), and +13 % at one texel per pixel.  So: large volumes only.
+    if (p.width < 16 || (uint64_t)p.grid.dim[0] * p.grid.dim[1] * p.grid.dim[2] <= (256ull << 20)) return 1u;
+    float scale = 0.0f;
+    for (int a = 0; a < 3; ++a) scale = fmaxf(scale, p.grid.tex_scale[a]);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *m = cameras[i].inverse_view_proj;
+        float d[2][3];
+        for (int k = 0; k < 2; ++k) {
+            const float sx = (((float)(p.width / 2 + (uint32_t)k) + 0.5f) / (float)p.width) * 2.0f - 1.0f;
+            const float sy = (1.0f - ((float)(p.height / 2) + 0.5f) / (float)p.height) * 2.0f - 1.0f;
+            float len = 0.0f;
+            for (int c = 0; c < 3; ++c) {
+                d[k][c] = m[0 + c] * sx + m[4 + c] * sy + m[8 + c] + m[12 + c];
+                len += d[k][c] * d[k][c];
+            }
+            len = sqrtf(len);
+            for (int c = 0; c < 3; ++c) d[k][c] /= len;
+        }
+        float angle = 0.0f, dist = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            angle += (d[1][c] - d[0][c]) * (d[1][c] - d[0][c]);
+            const float centre = p.grid.box_min[c] + 0.5f * p.grid.box_size[c];
+            dist += (cameras[i].position[c] - centre) * (cameras[i].position[c] - centre);
+        }
+        const float texels_per_pixel = sqrtf(angle) * sqrtf(dist) * scale;
+        if (!(texels_per_pixel <= 0.6f)) return 1u; // (NaN: one)
+    }
+    return 2u;
+}
+
 static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets, bool use_static)
 {
     int rc = bind(ctx);
@@ -797,6 +835,7 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, w, h, targets[0]->pitch);
     p.any_far = any_far_view(p, cameras, n);
+    p.rays = rays_for_batch(ctx, p, cameras, n);
     p.views = dev_views;
     p.diag_counters = diag ? reinterpret_cast<unsigned long long *>(ctx->flag_dev + 16) : nullptr; // bytes 64..127 of the 256-byte scratch
 
@@ -873,6 +912,7 @@ extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras,
     memset(&p, 0, sizeof p);
     fill_params(ctx, &p, width, height, (size_t)width * 4);
     p.any_far = any_far_view(p, cameras, n);
+    p.rays = rays_for_batch(ctx, p, cameras, n);
     p.views = ctx->views_dev + slot;
     HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, false, ctx->opt_skip != 0, ctx->stream));
     return VRM_OK;
@@ -1095,6 +1135,7 @@ extern "C" int vrm_set_option(vrm_ctx *ctx, int option, int64_t value)
     case VRM_OPT_DIAGNOSTICS: ctx->opt_diag = value; break;
     case VRM_OPT_CHUNK_STEPS: ctx->opt_chunk = value < 0 ? 0 : (value > 256 ? 256 : value); break;
     case VRM_OPT_PACKED_ALPHA: ctx->opt_packed = value != 0 ? 1 : 0; break;
+    case VRM_OPT_RAYS_PER_LANE: ctx->opt_rays = value == 1 || value == 2 ? value : 0; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;
@@ -1111,6 +1152,7 @@ extern "C" int vrm_get_option(vrm_ctx *ctx, int option, int64_t *value)
     case VRM_OPT_CHUNK_STEPS: *value = ctx->opt_chunk; break;
     case VRM_OPT_PACKED_ALPHA: *value = ctx->opt_packed; break;
     case VRM_OPT_COMPACT_SCALAR: *value = ctx->opt_compact; break;
+    case VRM_OPT_RAYS_PER_LANE: *value = ctx->opt_rays; break;
     default: vrm_set_error("unknown option %d", option); return VRM_ERR_INVALID;
     }
     return VRM_OK;

@@ -78,6 +78,9 @@ struct VrmMarchParams {
     uint32_t tiles_total(uint32_t views) const { return sblocks_x * sblocks_y * 64u * views; }
     uint32_t any_far;     // some view of the batch may be a far-camera view (|camera in texels| > 4096): launch the FAR instance too
     int32_t packed_alpha; // 1-channel march staged from the packed alpha bricks (default) or, 0, from the RGBA8 bricks
+    // rays per lane of the packed scalar march: 2 = wave tiles of 16x8 pixels, a lane marches two x-adjacent pixels through one
+    // staged box per chunk (the host chooses it where a pixel is narrower than ~0.6 texel in every view of the batch); else 1
+    uint32_t rays;
     // diagnostics build only (else nullptr): 8 counters the waves add to -- filtered samples, of those with alpha exactly 0,
     // chunk prologues, chunks staged, chunks passed over as empty, deep empty-space probes that found something, chunks
     // marched with global gathers (vrm_diag_read_counters)

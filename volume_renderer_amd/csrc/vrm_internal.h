@@ -47,7 +47,7 @@ struct vrm_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // options
-    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1, opt_compact = 1;
+    int64_t opt_kernel = 1, opt_skip = 1, opt_profile = 0, opt_diag = 0, opt_chunk = 0, opt_packed = 1, opt_compact = 1, opt_rays = 0;
 
     // profiling (VRM_OPT_PROFILE)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -27,8 +27,17 @@
 #ifndef VRM_WEIGHTS_FIRST
 #define VRM_WEIGHTS_FIRST 0 /* A/B: trilinear filter of the RGBA march as eight corner weights + byte * weight products */
 #endif
+#ifndef VRM_RAYS2_DEPTH
+#define VRM_RAYS2_DEPTH 15.0f /* texels of depth per chunk of the two-rays-per-lane march */
+#endif
 #ifndef VRM_SKIP_MAX_LEVEL
 #define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
+#endif
+#ifndef VRM_SKIP_START_LEVEL
+#define VRM_SKIP_START_LEVEL 2 /* the level a tile's first chunk is probed at: rays enter through empty space more often than not (A/B: 0) */
+#endif
+#ifndef VRM_SKIP_FALLBACK
+#define VRM_SKIP_FALLBACK 2 /* a failed deep probe drops ONE level and waits this many more empty chunks before it probes deeper again (A/B: 0 = back to level 0) */
 #endif
 #ifndef VRM_SKIP_ESCALATE
 #define VRM_SKIP_ESCALATE 1  /* consecutive empty chunks at one level before the next level is tried */
@@ -549,15 +558,25 @@ __device__ __forceinline__ void advance_exact(float &dt, bool &active, float t_m
 }
 
 // what the march kernel decides per chunk before it stages and samples (see `plan` in the kernel)
+template <int R>
 struct ChunkPlan {
-    int n_lane, kk, ilo[3], ihi[3], nx, ny, nz, pitch, slice, x0u;
+    int n_lane[R], kk, ilo[3], ihi[3], nx, ny, nz, pitch, slice, x0u;
     bool none, fits, interior, empty;
 };
 
 // One 8x8-pixel tile of one view, marched by one wave: `xcd` and `slot` say which (see "Tile order" below).
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
+// RAYS = 2: the tile is 16x8 pixels and a lane owns two x-adjacent pixels, whose rays it marches one after the other through
+// ONE staged box per chunk.  Where a pixel is narrower than a texel (a 2048^2 view of a 1024^3 volume: half a texel) the box
+// of 16x8 pixels is hardly larger than that of 8x8 -- its size is set by the slack, the +1 corner, the 16-texel staging
+// quads and the obliqueness of the view -- so the chunk prologue, the occupancy look-up and the staged bytes are shared by
+// twice the samples.  Which ray takes which step in which chunk does not change a ray's own dt sequence or what a sample
+// contributes: the image is bit-identical to the one-ray form (tests/test_gpu_parity.py).
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR, int RAYS>
 __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmViewDesc &v, const uint32_t xcd, const uint32_t slot)
 {
+    constexpr int R = RAYS;
+    static_assert(R == 1 || R == 2, "one or two rays per lane");
+    static_assert(R == 1 || !FAR, "far-camera views keep one ray per lane");
     // PACKED: the 1-channel march staged from the packed alpha bricks.  A "row unit" of the LDS tile is then a word of
     // four x-adjacent texels instead of one RGBA8 texel: a quarter of the staging bytes and of the tile's x extent.
     static_assert(!PACKED || ALPHA_ONLY, "the packed source holds the alpha channel only");
@@ -582,10 +601,16 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     const uint32_t sby = j / per_row, m = j - sby * per_row;
     const uint32_t sbx = ((xcd - sby) & 7u) + 8u * m;
     const uint32_t tx = sbx * 8u + (within & 7u), ty = sby * 8u + (within >> 3);
-    if (tx * 8u >= P.width || ty * 8u >= P.height) return; // wave-uniform
+    if (tx * (8u * R) >= P.width || ty * 8u >= P.height) return; // wave-uniform
     const uint32_t lane = threadIdx.x;
-    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-    const bool in_image = px < P.width && py < P.height;
+    const uint32_t py = ty * 8u + (lane >> 3);
+    uint32_t px[R];
+    bool in_image[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        px[r] = (tx * 8u + (lane & 7u)) * R + r; // (two rays: the lane's pixels are x-adjacent)
+        in_image[r] = px[r] < P.width && py < P.height;
+    }
     // Far cameras.  The texel coordinate u = dt*rs + bla cancels two terms of the size of bla (the camera position in
     // texels): beyond 4096 texels an ulp of them is 0.0005 texel and the one-FMA coordinate drifts away from the oracle's
     // (ro + rd*dt) * scale + bias by more than the f32 contract allows on high-contrast volumes.  Such views (hundreds of
@@ -596,43 +621,58 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                 fmaxf(fabsf(__builtin_fmaf(v.pos[1], g.tex_scale[1], g.tex_bias[1])),
                                       fabsf(__builtin_fmaf(v.pos[2], g.tex_scale[2], g.tex_bias[2]))));
     if ((uni(bla_max > 4096.0f ? 1 : 0) != 0) != FAR) return; // view-uniform
-    const Ray ray = setup_ray(v, g, in_image ? px : 0u, in_image ? py : 0u, P.width, P.height);
-
-    Accum acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t iters = 0, n_inside = 0, n_exec = 0;
+    Ray ray[R];
+    Accum acc[R];
+    uint32_t iters[R], n_inside[R], n_exec[R];
+    bool active[R];
+    float dt[R];
+    bool any_active = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ray[r] = setup_ray(v, g, in_image[r] ? px[r] : 0u, in_image[r] ? py : 0u, P.width, P.height);
+        acc[r] = {0.0f, 0.0f, 0.0f, 0.0f};
+        iters[r] = n_inside[r] = n_exec[r] = 0;
+        active[r] = in_image[r] && ray[r].hit;
+        dt[r] = ray[r].t_min;
+        any_active = any_active || active[r];
+    }
     // diagnostics build: per-lane count of filtered samples whose alpha came out exactly 0, and per-wave chunk statistics
     uint32_t n_zero = 0, st_chunks = 0, st_staged = 0, st_empty = 0, st_probe_fail = 0, st_fallback = 0, st_retry = 0;
     const float kexp = -(VRM_STEP_SIZE * P.attenuation) * LOG2E * (1.0f / 255.0f) * T22; // per 2^-22 texel level
     const TfRegs tf = tf_regs<USE_TF>(P);
-    bool active = in_image && ray.hit;
-    float dt = ray.t_min;
-    if (__builtin_amdgcn_ballot_w64(active) == 0ull) { // the tile misses the volume (half the tiles of a sphere view): clear colour
-        finish_colour<ALPHA_ONLY, USE_TF>(acc);
-        if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, 0u, 0u, 0u);
+    if (__builtin_amdgcn_ballot_w64(any_active) == 0ull) { // the tile misses the volume (half the tiles of a sphere view): clear colour
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            finish_colour<ALPHA_ONLY, USE_TF>(acc[r]);
+            if (in_image[r]) store_pixel<DIAG>(v, P, px[r], py, acc[r], ray[r], 0u, 0u, 0u);
+        }
         return;
     }
 
     // Per-step advance of a ray in texel space.  The 1 % slack covers the drift of the running f32 dt sum (an ulp
     // of dt per step, 0.4 % of a step at dt = 100).
-    float rs[3], du[3];
+    float rs[R][3], du[R][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        rs[a] = ray.rd[a] * g.tex_scale[a];
-        du[a] = rs[a] * (VRM_STEP_SIZE * 1.01f);
-    }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rs[r][a] = ray[r].rd[a] * g.tex_scale[a];
+            du[r][a] = rs[r][a] * (VRM_STEP_SIZE * 1.01f);
+        }
     // the ray origin in absolute texel coordinates: u(dt) = dt*rs + bla is the coordinate every staged sample is filtered at
+    // (the origin is the camera position: one for all rays)
     float bla[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) bla[a] = __builtin_fmaf(ray.ro[a], g.tex_scale[a], g.tex_bias[a]);
+    for (int a = 0; a < 3; ++a) bla[a] = __builtin_fmaf(ray[0].ro[a], g.tex_scale[a], g.tex_bias[a]);
     constexpr bool far_cam = FAR;
     const float box_slack = 0.01f + (far_cam ? bla_max * 0x1p-20f : 0.0f);
-    auto texel_coord = [&](const float dtv, float u[3]) __attribute__((always_inline)) {
+    auto texel_coord = [&](const float dtv, float u[3], const int r) __attribute__((always_inline)) {
         if (far_cam) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dtv, g.tex_scale[a], g.tex_bias[a]);
+            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(ray[r].ro[a] + ray[r].rd[a] * dtv, g.tex_scale[a], g.tex_bias[a]);
         } else {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(dtv, rs[a], bla[a]);
+            for (int a = 0; a < 3; ++a) u[a] = __builtin_fmaf(dtv, rs[r][a], bla[a]);
         }
     };
     // Front alignment.  Rays start on the entry faces of the box, so "the same number of steps for every ray" keeps
@@ -648,7 +688,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     int in_lim;
     {
         const uint32_t ka = (lane < 6u ? lane : 0u) >> 1;
-        const float ro_a = ka == 0 ? ray.ro[0] : ka == 1 ? ray.ro[1] : ray.ro[2];
+        const float ro_a = ka == 0 ? ray[0].ro[0] : ka == 1 ? ray[0].ro[1] : ray[0].ro[2];
         const float sc_a = ka == 0 ? g.tex_scale[0] : ka == 1 ? g.tex_scale[1] : g.tex_scale[2];
         const float bi_a = ka == 0 ? g.tex_bias[0] : ka == 1 ? g.tex_bias[1] : g.tex_bias[2];
         // (the ray origin is the camera position: the same for every lane)
@@ -664,8 +704,13 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         float amax[3], amin[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            amin[a] = active ? du[a] : __builtin_inff();
-            amax[a] = active ? du[a] : -__builtin_inff();
+            amin[a] = __builtin_inff();
+            amax[a] = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                amin[a] = active[r] ? (R == 1 ? du[r][a] : fminf(amin[a], du[r][a])) : amin[a];
+                amax[a] = active[r] ? (R == 1 ? du[r][a] : fmaxf(amax[a], du[r][a])) : amax[a];
+            }
             wave_minmax(amin[a], amax[a]);
         }
         float best = -1.0f;
@@ -680,13 +725,17 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                          : -(m_axis == 0 ? amax[0] : m_axis == 1 ? amax[1] : amax[2]);
         aligned = slowest > 0.25f * smax;
     }
-    const float du_m = sgn * (m_axis == 0 ? du[0] : m_axis == 1 ? du[1] : du[2]); // > 0 when aligned
+    float rs_m[R], inv_du_m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        rs_m[r] = sgn * (m_axis == 0 ? rs[r][0] : m_axis == 1 ? rs[r][1] : rs[r][2]);
+        const float du_m = rs_m[r] * (VRM_STEP_SIZE * 1.01f); // = sgn * du[m] (a sign is exact); > 0 when aligned
+        inv_du_m[r] = aligned ? 1.0f / du_m : 0.0f;
+    }
     // the plane coordinate of a sample, prog(dt) = sgn * u_m(dt) = fma(dt, sgn * rs_m, sgn * bla_m) (negation commutes with
     // rounding: bit-identical), from two per-lane registers chosen once per tile -- as a select on the major axis per chunk it
     // was three FMAs, two v_cndmask and six v_readlane of spilled lane masks
-    const float rs_m = sgn * (m_axis == 0 ? rs[0] : m_axis == 1 ? rs[1] : rs[2]);
     const float bla_m = sgn * (m_axis == 0 ? bla[0] : m_axis == 1 ? bla[1] : bla[2]);
-    const float inv_du_m = aligned ? 1.0f / du_m : 0.0f;
     // Boxes from the tile's geometry.  The rays of a tile are a pencil through the camera: at plane coordinate p (along the
     // major axis, see `prog` below) lane l is at u_a = bla_a + (p - p_cam) * B_l[a], B_l[a] = rs_l[a] / |rs_l[m]|, and a
     // chunk's samples lie between the plane of the rear-most lane and the plane the chunk ends at.  With the extremes of B
@@ -703,13 +752,20 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // camera's plane coordinate, +inf where this path is off.)
     float geo_bn = 0.0f, geo_bf = 0.0f, geo_c = 0.0f, geo_cl = 0.0f, geo_ch = 0.0f, p_cam = __builtin_inff();
     if (GEO && aligned) {
-        const float inv_m = sgn / (m_axis == 0 ? rs[0] : m_axis == 1 ? rs[1] : rs[2]); // 1 / |rs_m|: every active lane moves forward
+        float inv_m[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) inv_m[r] = sgn / (m_axis == 0 ? rs[r][0] : m_axis == 1 ? rs[r][1] : rs[r][2]); // 1 / |rs_m|: every active lane moves forward
         float bmn[3], bmx[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float b = rs[a] * inv_m;
-            bmn[a] = active ? b : __builtin_inff();
-            bmx[a] = active ? b : -__builtin_inff();
+            bmn[a] = __builtin_inff();
+            bmx[a] = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float b = rs[r][a] * inv_m[r];
+                bmn[a] = active[r] ? (R == 1 ? b : fminf(bmn[a], b)) : bmn[a];
+                bmx[a] = active[r] ? (R == 1 ? b : fmaxf(bmx[a], b)) : bmx[a];
+            }
             wave_minmax(bmn[a], bmx[a]);
         }
         const uint32_t k = lane < 6u ? lane : 0u, ka = k >> 1;
@@ -726,12 +782,14 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         geo_cl = upper ? -0x1p28f : (ka == 0 ? g.u_lo[0] : ka == 1 ? g.u_lo[1] : g.u_lo[2]) - 0.5f;
         geo_ch = upper ? (ka == 0 ? g.u_hi[0] : ka == 1 ? g.u_hi[1] : g.u_hi[2]) : 0x1p28f;
     }
-    int steps_left = VRM_MAX_STEP_AMOUNT; // wgsl:139: at most 5000 iterations per ray
+    int steps_left[R]; // wgsl:139: at most 5000 iterations per ray
+#pragma unroll
+    for (int r = 0; r < R; ++r) steps_left[r] = VRM_MAX_STEP_AMOUNT;
     // Empty space in long strides.  After an empty chunk the next one is tried 2^lvl times as deep and tested against level
     // lvl of the occupancy pyramid (cells 2^lvl times as wide: as many look-ups as a plain chunk); a deeper chunk that is not
     // empty costs one prologue and drops back to lvl 0, where chunks are staged and sampled.  How the march is cut into
     // chunks does not change what a sample contributes (see the steps below), so this is as exact as plain skipping.
-    int lvl = 0, lvl_run = 0;
+    int lvl = SKIP && VRM_SKIP_START_LEVEL > 0 && g.occ_off[VRM_SKIP_START_LEVEL] != 0 ? VRM_SKIP_START_LEVEL : 0, lvl_run = 0;
     // byte offset of pyramid level L in lane L of one register (indexed by the level as an array of the kernel argument it is a
     // scalar load and its round trip in every chunk prologue)
     const uint32_t occ_off_v = lane == 1u ? g.occ_off[1] : lane == 2u ? g.occ_off[2] : lane == 3u ? g.occ_off[3] : 0u;
@@ -745,38 +803,57 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     // One chunk's plan: steps per lane, the box, how it lies in the tile, whether it is empty.  A function of the ray state
     // (dt, active, steps left) and the stride level alone, so it can be made for the NEXT chunk while the current chunk's
     // box is still in flight (look-ahead below).
-    auto plan = [&](const float dt, const bool active, const int steps_left, const int lvl, ChunkPlan &q) __attribute__((always_inline)) {
-        float ua[3] = {0.0f, 0.0f, 0.0f};
-        float prog;
-        if (far_cam) {
-            texel_coord(dt, ua); // (the formula the samples are filtered at)
-            prog = sgn * (m_axis == 0 ? ua[0] : m_axis == 1 ? ua[1] : ua[2]);
-        } else {
-            prog = __builtin_fmaf(dt, rs_m, bla_m);
+    auto plan = [&](const float (&dt)[R], const bool (&active)[R], const int (&steps_left)[R], const int lvl, ChunkPlan<R> &q) __attribute__((always_inline)) {
+        float ua[R][3];
+        float prog[R];
+        float prog_min = __builtin_inff();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            ua[r][0] = ua[r][1] = ua[r][2] = 0.0f;
+            if (far_cam) {
+                texel_coord(dt[r], ua[r], r); // (the formula the samples are filtered at)
+                prog[r] = sgn * (m_axis == 0 ? ua[r][0] : m_axis == 1 ? ua[r][1] : ua[r][2]);
+            } else {
+                prog[r] = __builtin_fmaf(dt[r], rs_m[r], bla_m);
+            }
+            prog_min = active[r] ? (R == 1 ? prog[r] : fminf(prog_min, prog[r])) : prog_min;
         }
-        const float rear = aligned ? wave_min(active ? prog : __builtin_inff()) : 0.0f;
+        const float rear = aligned ? wave_min(prog_min) : 0.0f;
         // chunk length = the steps of the rear-most lane: the wave's learned depth for plain chunks, strides in empty space
         int kk = lvl > 0 ? (int)P.chunk_steps << lvl : kk_base;
-        int &n_lane = q.n_lane;      // steps of this lane in this chunk
+        int (&n_lane)[R] = q.n_lane; // steps of this lane's rays in this chunk
         int *ilo = q.ilo, *ihi = q.ihi;
         int &nx = q.nx, &ny = q.ny, &nz = q.nz, &pitch = q.pitch, &slice = q.slice;
         int &x0u = q.x0u; // first staged column in row units (texels; words of 4 texels when PACKED)
         bool &none = q.none, &fits = q.fits, &interior = q.interior;
         // texel-space bounding box [lo, hi] of everything `nl` steps of every lane can touch; returns this lane's
         // "every step stays inside the volume (slab) with margin"
-        auto chunk_box = [&](int nl, int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
+        auto chunk_box = [&](const int (&nl)[R], int lo[3], int hi[3]) __attribute__((always_inline)) -> bool {
             // texels floor(u) and floor(u)+1 are read; samples outside [-0.5, dim-0.5) fail the in-box test.  Per lane only
             // the float extent of its steps; the wave's extent is reduced as floats and floored once, in lane 63, so the
             // bounds land in SGPRs as integers.  (z of a slab-partitioned volume: samples outside the slab's own range fail
             // the test too, so a chunk that lies in another rank's slab degenerates to `none` and only advances dt.)
-            const bool has = nl > 0;
-            const float nlf = (float)nl;
             float mn[3], mx[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float ue = __builtin_fmaf(nlf, du[a], ua[a]);
-                mn[a] = has ? fminf(ua[a], ue) : __builtin_inff();
-                mx[a] = has ? fmaxf(ua[a], ue) : -__builtin_inff();
+                mn[a] = __builtin_inff();
+                mx[a] = -__builtin_inff();
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool has = nl[r] > 0;
+                const float nlf = (float)nl[r];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float ue = __builtin_fmaf(nlf, du[r][a], ua[r][a]);
+                    if (R == 1) {
+                        mn[a] = has ? fminf(ua[r][a], ue) : __builtin_inff();
+                        mx[a] = has ? fmaxf(ua[r][a], ue) : -__builtin_inff();
+                    } else {
+                        mn[a] = has ? fminf(mn[a], fminf(ua[r][a], ue)) : mn[a];
+                        mx[a] = has ? fmaxf(mx[a], fmaxf(ua[r][a], ue)) : mx[a];
+                    }
+                }
             }
             wave_minmax3f_lane63(mn, mx);
             bool inter = true;
@@ -842,9 +919,9 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             return (__builtin_amdgcn_ballot_w64((iv ^ flip) >= in_lim) & 0x3full) == 0x3full;
         };
         // the plane sits (kk + 1/2) of the fastest lane's steps ahead of the rear-most lane: that lane takes kk steps
-        auto lane_steps = [&](int k) __attribute__((always_inline)) -> int {
-            const float ahead = aligned ? (rear + ((float)k + 0.5f) * smax - prog) * inv_du_m : (float)k;
-            return active ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)k), steps_left) : 0;
+        auto lane_steps = [&](int k, const int r) __attribute__((always_inline)) -> int {
+            const float ahead = aligned ? (rear + ((float)k + 0.5f) * smax - prog[r]) * inv_du_m[r] : (float)k;
+            return active[r] ? min((int)__builtin_amdgcn_fmed3f(ahead, 0.0f, (float)k), steps_left[r]) : 0;
         };
         // (a camera inside the volume marches from t_min < 0, behind itself, where (p - p_cam) * B changes its sense)
         // (Not for a slab-partitioned volume either: its waves are active in part for much of their way -- rays enter and
@@ -856,8 +933,11 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         for (;;) {
             if (use_geo) interior = geo_box(kk, ilo, ihi);
             else {
-                if (!far_cam) texel_coord(dt, ua); // (only the reduction over the lanes' own positions needs all three axes)
-                n_lane = lane_steps(kk);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!far_cam) texel_coord(dt[r], ua[r], r); // (only the reduction over the lanes' own positions needs all three axes)
+                    n_lane[r] = lane_steps(kk, r);
+                }
                 interior = chunk_box(n_lane, ilo, ihi); // every step of every lane stays inside the volume (slab) with margin
             }
             none = ihi[0] - ilo[0] < 1 || ihi[1] - ilo[1] < 1 || ihi[2] - ilo[2] < 1; // whole chunk lies outside the box
@@ -876,14 +956,20 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             kk = (3 * kk) >> 2; // 3/4 steps down to 1 (2 -> 1 as 6 >> 2)
             if (DIAG) ++st_retry;
         }
-        if (use_geo) n_lane = lane_steps(kk);
+        if (use_geo) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) n_lane[r] = lane_steps(kk, r);
+        }
         if (none) empty = true;
         else {
             if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
                 kk = 8;
-                n_lane = active ? min(8, steps_left) : 0;
-                // the box above is that of the ONE step that did not fit; the emptiness test must cover all 8
-                if (!far_cam) texel_coord(dt, ua);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    n_lane[r] = active[r] ? min(8, steps_left[r]) : 0;
+                    // the box above is that of the ONE step that did not fit; the emptiness test must cover all 8
+                    if (!far_cam) texel_coord(dt[r], ua[r], r);
+                }
                 (void)chunk_box(n_lane, ilo, ihi);
             }
             if (SKIP) empty = box_is_empty();
@@ -891,13 +977,19 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         q.kk = kk;
         q.empty = empty;
     };
-    ChunkPlan cp;
+    ChunkPlan<R> cp;
 #ifdef VRM_LOOKAHEAD
-    ChunkPlan cp_next;
+    static_assert(R == 1, "the look-ahead experiment is a one-ray build");
+    ChunkPlan<R> cp_next;
     bool have_next = false;
 #endif
     for (;;) {
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        {
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) any = any || active[r];
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) break;
+        }
         // Issue priority by phase: a wave in its step loop goes before a wave that plans or stages (s_setprio 1 / 0).  The step
         // loops are what the SIMD's VALU is short of; a planning wave mostly waits on reductions and memory anyway.
         // C3 0.367 -> 0.359 ms/view, C4 1.088 -> 1.057; the level (1..3) makes no difference, the other polarity loses, and so does
@@ -910,29 +1002,30 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         } else
 #endif
         {
-            if (!DIAG && g.slab) {
+            // (two rays per lane: the launcher keeps slab-partitioned volumes on the one-ray form)
+            if (R == 1 && !DIAG && g.slab) {
                 // Slab-partitioned volume: this rank marches the whole volume's lattice but blends only its slab's samples.
                 // (The diagnostics build walks every step so that its per-ray counts stay those of the unpartitioned march.)
-                const float uz = __builtin_fmaf(dt, rs[2], bla[2]), dz = du[2], lo1 = g.u_lo[2] - 1.0f, hi1 = g.u_hi[2] + 1.0f; // one texel of margin
+                const float uz = __builtin_fmaf(dt[0], rs[0][2], bla[2]), dz = du[0][2], lo1 = g.u_lo[2] - 1.0f, hi1 = g.u_hi[2] + 1.0f; // one texel of margin
                 // past the slab and moving away: nothing left to blend, the accumulators are final
-                if (dz > 0.0f ? uz >= hi1 : (dz < 0.0f && uz < lo1)) active = false;
-                if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+                if (dz > 0.0f ? uz >= hi1 : (dz < 0.0f && uz < lo1)) active[0] = false;
+                if (__builtin_amdgcn_ballot_w64(active[0]) == 0ull) break;
                 // before the slab: advance the running dt sum up to the slab's entry plane without a chunk prologue per K
                 // steps (du carries 1 % slack, so the step count errs on the short side)
                 float ff = 0.0f;
                 if (dz > 0.0f && uz < lo1) ff = (lo1 - uz) / dz;
                 else if (dz < 0.0f && uz >= hi1) ff = (hi1 - uz) / dz;
-                const int nff = uni((int)fminf(wave_min(active ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
+                const int nff = uni((int)fminf(wave_min(active[0] ? ff : __builtin_inff()), (float)VRM_MAX_STEP_AMOUNT)) - 1;
                 if (nff > 0) {
-                    advance_exact(dt, active, ray.t_max, nff);
-                    steps_left -= nff;
-                    active = active && steps_left > 0;
+                    advance_exact(dt[0], active[0], ray[0].t_max, nff);
+                    steps_left[0] -= nff;
+                    active[0] = active[0] && steps_left[0] > 0;
                     continue;
                 }
             }
             plan(dt, active, steps_left, lvl, cp);
         }
-        int &n_lane = cp.n_lane;
+        int (&n_lane)[R] = cp.n_lane;
         const int *ilo = cp.ilo;
         const int nx = cp.nx, ny = cp.ny, nz = cp.nz, pitch = cp.pitch, slice = cp.slice, x0u = cp.x0u, kk = cp.kk;
         const bool fits = cp.fits, interior = cp.interior;
@@ -943,8 +1036,8 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         }
         if (DIAG) ++st_chunks;
         if (SKIP && lvl > 0 && !empty) { // the deep probe found something (or could not be tested): back to plain chunks
-            lvl = 0;
-            lvl_run = 0;
+            lvl = VRM_SKIP_FALLBACK ? lvl - 1 : 0; // (A/B: one level down instead -- the level that was last found empty)
+            lvl_run = VRM_SKIP_FALLBACK ? -VRM_SKIP_FALLBACK : 0; // (... and that many more empty chunks before the next probe)
             if (DIAG) ++st_probe_fail;
             continue; // nothing was advanced
         }
@@ -1024,12 +1117,12 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                 // chunk's steps is known before they run (the dt lattice and the geometric end of the ray: advance_exact), and
                 // a staged chunk is followed by a plain one (lvl 0).  The plan's occupancy look-up queues behind the DMA.
                 if (!ERT && !DIAG && !g.slab) {
-                    float dt1 = dt;
-                    bool a1 = active;
-                    advance_exact(dt1, a1, ray.t_max, n_lane);
-                    const int sl1 = steps_left - n_lane;
-                    a1 = a1 && sl1 > 0;
-                    if (__builtin_amdgcn_ballot_w64(a1) != 0ull) {
+                    float dt1[1] = {dt[0]};
+                    bool a1[1] = {active[0]};
+                    advance_exact(dt1[0], a1[0], ray[0].t_max, n_lane[0]);
+                    const int sl1[1] = {steps_left[0] - n_lane[0]};
+                    a1[0] = a1[0] && sl1[0] > 0;
+                    if (__builtin_amdgcn_ballot_w64(a1[0]) != 0ull) {
                         plan(dt1, a1, sl1, 0, cp_next);
                         have_next = true;
                     }
@@ -1083,22 +1176,25 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
         }
         if (empty) {
             // nothing to sample in this chunk: advance the running dt sum exactly as the loop would (wgsl:181-186)
-            if (!DIAG) advance_exact(dt, active, ray.t_max, n_lane); // (the diagnostics build counts in-box samples per step)
-            else
-            for (int j = 0; j < kk; ++j) {
-                if (j < n_lane && active) {
-                    if (DIAG) {
-                        ++iters;
-                        const float p0 = ray.ro[0] + ray.rd[0] * dt, p1 = ray.ro[1] + ray.rd[1] * dt, p2 = ray.ro[2] + ray.rd[2] * dt;
-                        n_inside += ((p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
-                                     (p1 < g.box_max[1]) & (p2 < g.in_max_z)) ? 1u : 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!DIAG) advance_exact(dt[r], active[r], ray[r].t_max, n_lane[r]); // (the diagnostics build counts in-box samples per step)
+                else
+                for (int j = 0; j < kk; ++j) {
+                    if (j < n_lane[r] && active[r]) {
+                        if (DIAG) {
+                            ++iters[r];
+                            const float p0 = ray[r].ro[0] + ray[r].rd[0] * dt[r], p1 = ray[r].ro[1] + ray[r].rd[1] * dt[r], p2 = ray[r].ro[2] + ray[r].rd[2] * dt[r];
+                            n_inside[r] += ((p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
+                                            (p1 < g.box_max[1]) & (p2 < g.in_max_z)) ? 1u : 0u;
+                        }
+                        dt[r] += VRM_STEP_SIZE;
+                        active[r] = !(dt[r] >= ray[r].t_max);
                     }
-                    dt += VRM_STEP_SIZE;
-                    active = !(dt >= ray.t_max);
                 }
+                steps_left[r] -= n_lane[r]; // a lane that stopped early is inactive anyway
+                active[r] = active[r] && steps_left[r] > 0;
             }
-            steps_left -= n_lane; // a lane that stopped early is inactive anyway
-            active = active && steps_left > 0;
             if (SKIP && VRM_SKIP_MAX_LEVEL > 0) {
                 // (level L exists only if the pyramid fits 32-bit offsets: occ_off[L] != 0)
                 if (++lvl_run >= VRM_SKIP_ESCALATE && lvl < VRM_SKIP_MAX_LEVEL && __builtin_amdgcn_readlane((int)occ_off_v, uni(lvl + 1)) != 0) { ++lvl; lvl_run = 0; }
@@ -1126,34 +1222,35 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
             const float amax4 = (float)(4 * ((nz - 2) * slice + (ny - 2) * pitch) + (PACKED ? 4 * nx - 2 : 4 * (nx - 2)));
             const char *tile_b = reinterpret_cast<const char *>(tile);
             auto ld = [&](int byte_off) -> uint32_t { return *reinterpret_cast<const uint32_t *>(tile_b + byte_off); };
-            auto steps = [&](auto interior_c) {
+            auto steps = [&](auto interior_c, auto ray_c) {
                 constexpr bool INTERIOR = decltype(interior_c)::value;
+                constexpr int r = decltype(ray_c)::value;
                 // (The lane's state inside the loop is ONE vector register: the step it stops at, -1 once the ray has ended.  As
                 // `j < n_lane && active` with the mask `active` updated per step the loop carried 20 scalar instructions per
                 // sample -- see the staging loop above for what they cost.)
-                int lim = active ? n_lane : 0;
+                int lim = active[r] ? n_lane[r] : 0;
                 const int kku = uni(kk); // (wave-uniform by construction; said so, the loop control is scalar)
                 for (int j = 0; j < kku; ++j) {
                     if (j < lim) {
-                        if (DIAG) ++iters;
+                        if (DIAG) ++iters[r];
                         bool inside = true;
                         if constexpr (!INTERIOR) {
-                            const float p0 = ray.ro[0] + ray.rd[0] * dt;
-                            const float p1 = ray.ro[1] + ray.rd[1] * dt;
-                            const float p2 = ray.ro[2] + ray.rd[2] * dt;
+                            const float p0 = ray[r].ro[0] + ray[r].rd[0] * dt[r];
+                            const float p1 = ray[r].ro[1] + ray[r].rd[1] * dt[r];
+                            const float p2 = ray[r].ro[2] + ray[r].rd[2] * dt[r];
                             inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
                                      (p1 < g.box_max[1]) & (p2 < g.in_max_z);
                         }
                         bool done = false;
                         if (inside) {
-                            if (DIAG) { ++n_inside; ++n_exec; }
+                            if (DIAG) { ++n_inside[r]; ++n_exec[r]; }
                             float uu[3];
                             if constexpr (FAR) {
 #pragma unroll
-                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(ray.ro[a] + ray.rd[a] * dt, g.tex_scale[a], g.tex_bias[a]);
+                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(ray[r].ro[a] + ray[r].rd[a] * dt[r], g.tex_scale[a], g.tex_bias[a]);
                             } else {
 #pragma unroll
-                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(dt, rs[a], bla[a]);
+                                for (int a = 0; a < 3; ++a) uu[a] = __builtin_fmaf(dt[r], rs[r][a], bla[a]);
                             }
                             const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                             const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
@@ -1178,7 +1275,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                              : "v"(tb + (uint32_t)a0), "v"(tb + (uint32_t)a1), "v"(tb + (uint32_t)a2), "v"(tb + (uint32_t)a3)
                                              : "memory");
                                 float a255 = 1.0f;
-                                done = shade_bytes<USE_TF, ERT>(t, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
+                                done = shade_bytes<USE_TF, ERT>(t, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r], DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             } else {
                                 uint32_t c[8];
@@ -1187,55 +1284,71 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                                 c[4] = ld(a2); c[5] = ld(a2 + 4);
                                 c[6] = ld(a3); c[7] = ld(a3 + 4);
                                 float a255 = 1.0f;
-                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc, DIAG ? &a255 : nullptr);
+                                done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r], DIAG ? &a255 : nullptr);
                                 if (DIAG) n_zero += a255 == 0.0f ? 1u : 0u;
                             }
                         }
                         // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
-                        dt += VRM_STEP_SIZE;
-                        lim = (done || dt >= ray.t_max) ? -1 : lim;
+                        dt[r] += VRM_STEP_SIZE;
+                        lim = (done || dt[r] >= ray[r].t_max) ? -1 : lim;
                     }
                 }
-                active = active && lim >= 0;
+                active[r] = active[r] && lim >= 0;
             };
-            if (interior) steps(std::true_type{});
-            else steps(std::false_type{});
+            // (two rays: one after the other through the same staged box)
+            if (interior) {
+                steps(std::true_type{}, std::integral_constant<int, 0>{});
+                if constexpr (R > 1) steps(std::true_type{}, std::integral_constant<int, R - 1>{});
+            } else {
+                steps(std::false_type{}, std::integral_constant<int, 0>{});
+                if constexpr (R > 1) steps(std::false_type{}, std::integral_constant<int, R - 1>{});
+            }
         } else {
             // box too large for the LDS tile (far-away camera: a pixel spans many voxels): gather from global memory
+#pragma unroll
+            for (int r = 0; r < R; ++r)
             for (int j = 0; j < kk; ++j) {
-                if (j < n_lane && active) {
-                    if (DIAG) ++iters;
-                    const float p0 = ray.ro[0] + ray.rd[0] * dt;
-                    const float p1 = ray.ro[1] + ray.rd[1] * dt;
-                    const float p2 = ray.ro[2] + ray.rd[2] * dt;
+                if (j < n_lane[r] && active[r]) {
+                    if (DIAG) ++iters[r];
+                    const float p0 = ray[r].ro[0] + ray[r].rd[0] * dt[r];
+                    const float p1 = ray[r].ro[1] + ray[r].rd[1] * dt[r];
+                    const float p2 = ray[r].ro[2] + ray[r].rd[2] * dt[r];
                     const bool inside = (p0 >= g.box_min[0]) & (p1 >= g.box_min[1]) & (p2 >= g.in_min_z) & (p0 < g.box_max[0]) &
                                         (p1 < g.box_max[1]) & (p2 < g.in_max_z);
                     bool done = false;
                     if (inside) {
-                        if (DIAG) { ++n_inside; ++n_exec; }
+                        if (DIAG) { ++n_inside[r]; ++n_exec[r]; }
                         // the same filter coordinate as the staged path: which path a sample takes depends on the chunking
                         float uu[3];
-                        texel_coord(dt, uu);
+                        texel_coord(dt[r], uu, r);
                         const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
                         if (PACKED) fetch_global_alpha(g, (int)f0, (int)f1, (int)f2, c); // (the alpha byte is all the 1-channel filter reads)
                         else fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc);
+                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r]);
                     }
                     // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
-                    dt += VRM_STEP_SIZE;
-                    active = !(done || dt >= ray.t_max);
+                    dt[r] += VRM_STEP_SIZE;
+                    active[r] = !(done || dt[r] >= ray[r].t_max);
                 }
             }
         }
-        steps_left -= n_lane; // a lane that stopped early is inactive anyway
-        active = active && steps_left > 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            steps_left[r] -= n_lane[r]; // a lane that stopped early is inactive anyway
+            active[r] = active[r] && steps_left[r] > 0;
+        }
     }
-    finish_colour<ALPHA_ONLY, USE_TF>(acc);
-    if (in_image) store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside, n_exec);
+    unsigned long long n_exec_lane = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        finish_colour<ALPHA_ONLY, USE_TF>(acc[r]);
+        if (in_image[r]) store_pixel<DIAG>(v, P, px[r], py, acc[r], ray[r], iters[r], n_inside[r], n_exec[r]);
+        n_exec_lane += n_exec[r];
+    }
     if (DIAG && P.diag_counters) { // vrm_diag_read_counters: one atomic per counter and wave
-        unsigned long long e = n_exec, z = n_zero;
+        unsigned long long e = n_exec_lane, z = n_zero;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             e += __shfl_down(e, off, 64);
@@ -1261,7 +1374,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
 //    the other XCDs' queues.  No workgroup waits behind another XCD's slow tiles (the hardware dispatcher hands workgroups
 //    out in order) and the launch has no tail in which most of the chip idles.  Every wave leaves when all eight queues
 //    are empty; a tile is marched exactly once whichever wave claims it, so the image does not depend on the mode.
-template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR>
+template <bool ALPHA_ONLY, bool USE_TF, bool DIAG, bool SKIP, int CAP, bool PACKED, bool ERT, bool FAR, int RAYS = 1>
 #ifdef VRM_AB_LDS_PAD
 __global__ void __launch_bounds__(64, 2) march_lds_kernel
 #else
@@ -1271,7 +1384,7 @@ __global__ void __launch_bounds__(64, (163840 / (CAP * 4) / 4 > 8 ? 8 : 163840 /
 (const VrmMarchParams P)
 {
     if (P.queue == nullptr) {
-        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, P.views[blockIdx.y], blockIdx.x & 7u, blockIdx.x >> 3);
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR, RAYS>(P, P.views[blockIdx.y], blockIdx.x & 7u, blockIdx.x >> 3);
         return;
     }
     const uint32_t per_view = P.sblocks_x * P.sblocks_y * 8u; // tile slots of one view in one XCD's list
@@ -1301,7 +1414,7 @@ __global__ void __launch_bounds__(64, (163840 / (CAP * 4) / 4 > 8 ? 8 : 163840 /
             continue;
         }
         const uint32_t view = q / per_view;
-        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR>(P, P.views[view], xcd, q - view * per_view);
+        march_tile<ALPHA_ONLY, USE_TF, DIAG, SKIP, CAP, PACKED, ERT, FAR, RAYS>(P, P.views[view], xcd, q - view * per_view);
     }
 }
 
@@ -1690,12 +1803,15 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         const dim3 grid(p.tiles_x * p.tiles_y, n_views, 1), block(256, 1, 1);
         hipLaunchKernelGGL((march_linear_kernel<A, T, D>), grid, block, 0, stream, p);
     } else {
-        const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1), block(64, 1, 1);
+        const dim3 block(64, 1, 1);
         // texels a ray advances per step (the step is 0.001 world units whatever the resolution, wgsl:126)
         float tps = 0.0f;
         for (int a = 0; a < 3; ++a) tps = fmaxf(tps, VRM_STEP_SIZE * p.grid.tex_scale[a]);
-#define VRM_LDS(CAPV, DEPTH, PK)                                                                                  \
+#define VRM_LDS(CAPV, DEPTH, PK, NR)                                                                              \
     do {                                                                                                          \
+        /* two rays per lane: wave tiles of 16x8 pixels, super-blocks of 128x64 */                                 \
+        if ((NR) == 2) p.sblocks_x = (((p.width + 127u) / 128u) + 7u) & ~7u;                                       \
+        const dim3 grid(p.sblocks_x * p.sblocks_y * 64u, n_views, 1);                                              \
         /* chunk length: about DEPTH texels of depth per chunk unless the caller fixed it */                      \
         if (p.chunk_steps == 0) p.chunk_steps = (uint32_t)fminf(fmaxf(floorf((DEPTH) / tps + 0.5f), 2.0f), 64.0f); \
         /* tile queues: as many one-wave workgroups as the chip holds at CAPV words of LDS each.  Variant 1 chooses:     \
@@ -1708,10 +1824,11 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         if ((uint64_t)p.sblocks_x * p.sblocks_y * 64u * n_views >= (1ull << 32)) p.queue = nullptr;                \
         const dim3 gridq(p.queue ? min_u32(p.tiles_total(n_views), resident_waves((CAPV) * 4u)) : grid.x, p.queue ? 1u : grid.y, 1); \
         if (p.queue) (void)hipMemsetAsync(p.queue, 0, VRM_QUEUE_BYTES, stream);                                               \
-        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false>), gridq, block, 0, stream, p);   \
-        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false>), gridq, block, 0, stream, p);       \
-        /* views of far-away cameras are left to the FAR instance (its waves take only those) */                  \
-        if (p.any_far) {                                                                                          \
+        if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, E, false, NR>), gridq, block, 0, stream, p);   \
+        else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, E, false, NR>), gridq, block, 0, stream, p);       \
+        /* views of far-away cameras are left to the FAR instance (its waves take only those; one ray per lane: the   \
+         * host asks for two rays only when no view of the batch is far) */                                        \
+        if (p.any_far && (NR) == 1) {                                                                             \
             if (p.queue) (void)hipMemsetAsync(p.queue, 0, VRM_QUEUE_BYTES, stream);                                           \
             if (skip) hipLaunchKernelGGL((march_lds_kernel<A, T, D, true, CAPV, PK, true, true>), gridq, block, 0, stream, p);  \
             else hipLaunchKernelGGL((march_lds_kernel<A, T, D, false, CAPV, PK, true, true>), gridq, block, 0, stream, p);      \
@@ -1721,7 +1838,7 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
         // CU) is the measured optimum for 256^3 .. 1024^3 volumes; variant 2 keeps the 8 KB tile (20 waves per CU, 5 per
         // SIMD) selectable for A/B runs (VRM_OPT_KERNEL): more resident waves do not pay for the shallower chunks.
         if (variant == 2) {
-            VRM_LDS(2048, 6.0f, false);
+            VRM_LDS(2048, 6.0f, false, 1);
         } else {
             // 1-channel march (scalar volume or transfer function): staged from the packed alpha bricks -- a quarter of
             // the bytes and of the tile's x extent, so 15 texels of depth pay where the RGBA tile holds 8 (measured optima:
@@ -1730,11 +1847,19 @@ void launch_variant(VrmMarchParams p, uint32_t n_views, int variant, bool skip, 
             bool done = false;
             if constexpr (A) {
                 if (p.grid.abricks != nullptr && p.packed_alpha != 0) {
-                    VRM_LDS(VRM_CAP_PACKED, 15.0f, true);
+                    // two rays per lane where the host found every view's pixels narrower than ~0.6 texel (scalar volumes without
+                    // the transfer function: that instance has no registers to spare); never for far or slab-partitioned views
+                    bool two = false;
+                    if constexpr (!T) two = p.rays == 2u && !p.any_far && !p.grid.slab;
+                    if (two) {
+                        if constexpr (!T) VRM_LDS(VRM_CAP_PACKED, VRM_RAYS2_DEPTH, true, 2);
+                    } else {
+                        VRM_LDS(VRM_CAP_PACKED, 15.0f, true, 1);
+                    }
                     done = true;
                 }
             }
-            if (!done) VRM_LDS(VRM_CAP_DEFAULT, 8.0f, false); // 10 KB -> 16 waves/CU (variant 1, the default)
+            if (!done) VRM_LDS(VRM_CAP_DEFAULT, 8.0f, false, 1); // 10 KB -> 16 waves/CU (variant 1, the default)
         }
 #undef VRM_LDS
     }
