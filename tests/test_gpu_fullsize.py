@@ -250,5 +250,7 @@ def test_c5_resolution_fallback_chunks_skip_exactly(vr, orc):
     r.close()
     assert out["skip"][..., 3].max() > 0.05
     assert np.array_equal(out["skip"], out["noskip"])
-    assert np.abs(out["skip"] - out["gather"]).max() < 2e-6       # same samples, filter arithmetic in another order
-    assert np.abs(out["rgba_skip"] - out["gather"]).max() < 2e-6
+    # same samples through the global-gather baseline: its filter interpolates x as difference + product and it carries alpha,
+    # the march two products and the transmittance (round 3) -- equal to a few f32 roundings of a 0..1 value
+    assert np.abs(out["skip"] - out["gather"]).max() < 5e-6
+    assert np.abs(out["rgba_skip"] - out["gather"]).max() < 5e-6

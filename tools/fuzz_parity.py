@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc  # noqa: E402
 import volume_renderer_amd as vr  # noqa: E402
-from test_gpu_parity import check, configure, draw  # noqa: E402
+from test_gpu_parity import F32_SEEN, check, configure, draw  # noqa: E402
 from volume_renderer_amd import synth  # noqa: E402
 
 
@@ -108,6 +108,10 @@ def main():
         else:
             if case % 10 == 0:
                 print("ok  ", desc, flush=True)
+    if F32_SEEN:
+        d = np.sort(np.asarray(F32_SEEN))
+        print("f32 deviation from the oracle over %d checks: median %.2e, 99 %% %.2e, 99.9 %% %.2e, max %.2e; above 5e-5: %d, above 1e-4: %d"
+              % (len(d), d[len(d) // 2], d[int(0.99 * (len(d) - 1))], d[int(0.999 * (len(d) - 1))], d[-1], int((d > 5e-5).sum()), int((d > 1e-4).sum())), flush=True)
     # ---- sort-last: production-kernel partials of random z slabs (fast-forward to the slab, stop past it) against
     # the oracle's slab partials, and their "over" against the oracle's unpartitioned accumulators ----------------
     from volume_renderer_amd import sortlast

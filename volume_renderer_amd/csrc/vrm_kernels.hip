@@ -33,6 +33,16 @@
 #ifndef VRM_SKIP_MAX_LEVEL
 #define VRM_SKIP_MAX_LEVEL 3 /* deepest occupancy level used for empty-space strides (0 = plain chunk-by-chunk skipping) */
 #endif
+#ifndef VRM_XLERP_PRODUCTS
+#define VRM_XLERP_PRODUCTS 1 /* x interpolation of the byte-tile filter as two products instead of difference + product (A/B: 0) */
+#endif
+#ifndef VRM_TRANSMITTANCE
+/* A/B, measured and NOT adopted: kernels without the early exit carry the transmittance T = 1 - alpha (T *= e, weight = T - T*e:
+ * two instructions fewer per sample, -1 % on C3, -1.5 % on C4) -- but the weight then carries the rounding of T*e, not of
+ * 1 - e, and the f32 accumulators drift from the oracle's twice as far (fuzz seed 41, 1268 checks: 99.9 % 5.6e-5 -> 1.07e-4,
+ * max 7.0e-5 -> 1.26e-4, four cases beyond the 1e-4 contract; profiles/r3/transmittance.txt) */
+#define VRM_TRANSMITTANCE 0
+#endif
 #ifndef VRM_SKIP_START_LEVEL
 #define VRM_SKIP_START_LEVEL 2 /* the level a tile's first chunk is probed at: rays enter through empty space more often than not (A/B: 0) */
 #endif
@@ -238,9 +248,13 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     const float a22 = tri(std::integral_constant<int, 3>{});
     if (a_out) *a_out = a22;
     // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a22 * kexp22)
-    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a22 * kexp22);
-    const float om = 1.0f - acc.alpha;
-    const float w = om * alpha_src;
+    const float e = __builtin_amdgcn_exp2f(a22 * kexp22);
+    const float alpha_src = 1.0f - e;
+    // (TRANSMITTANCE: acc.alpha holds T = 1 - alpha; T' = T * e and the sample's weight (1 - alpha) * alpha_src = T - T')
+    constexpr bool TR = !ERT && VRM_TRANSMITTANCE != 0;
+    const float om = TR ? acc.alpha : 1.0f - acc.alpha;
+    const float t1 = om * e;
+    const float w = TR ? om - t1 : om * alpha_src;
     if (USE_TF) {
         tf_blend(a22, w, P, acc);
     } else if (ALPHA_ONLY) {
@@ -252,7 +266,7 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         acc.cg = __builtin_fmaf(w, tri(std::integral_constant<int, 1>{}), acc.cg);
         acc.cb = __builtin_fmaf(w, tri(std::integral_constant<int, 2>{}), acc.cb);
     }
-    acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
+    acc.alpha = TR ? t1 : __builtin_fmaf(om, alpha_src, acc.alpha);
     // wgsl:176.  Without ERT the launcher has established that no sample can reach alpha_src >= 0.5 (attenuation < 690), and
     // then alpha never rounds up to 1.0: the test is dead and left out.
     return ERT ? acc.alpha >= 1.0f : false;
@@ -262,34 +276,50 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
 // t[2r + 1] are the alpha bytes of texels x and x + 1 of row r (rows: y0z0, y1z0, y0z1, y1z1), each read by its own
 // ds_read_u8.  A zero-extended byte IS the f32 denormal b * 2^-149, so the filter is plain full-rate f32 arithmetic with
 // no conversion at all: the difference of two denormals is exact, a multiply by 2^127 and an FMA with the 2^127-scaled
-// weight bring them into the normal range.  Same values, same operations as shade<true, USE_TF> on the RGBA words (and as
-// the alignbyte + SDWA form this replaces: 8 ds_read_u8 cost the LDS what 4 ds_read2_b32 did, tools/probes/valu_probe2.hip).
+// weight bring them into the normal range.  (8 ds_read_u8 cost the LDS what 4 ds_read2_b32 did, tools/probes/valu_probe2.hip.)
+// Every sample of a PACKED instance goes through this function, the global-gather fallback chunks included: the x
+// interpolation rounds differently from shade<true, USE_TF>'s (two products against difference + product), and a sample's
+// contribution must not depend on how the march was cut into chunks.
 template <bool USE_TF, bool ERT>
 __device__ __forceinline__ bool shade_bytes(const uint32_t t[8], float wx, float wy, float wz, float kexp22, const TfRegs &P,
                                             Accum &acc, float *a_out = nullptr)
 {
     const float wxs = wx * 0x1p127f;
+#if VRM_XLERP_PRODUCTS
+    // b0 * (1 - wx) + b1 * wx with both weights scaled by 2^127: a multiply and an FMA per row instead of a subtraction, a
+    // multiply and an FMA (-3 instructions per sample; continuous arithmetic, another rounding of the same value)
+    const float w0s = __builtin_fmaf(-wx, 0x1p127f, 0x1p127f);
+    auto xlerp = [&](uint32_t t0, uint32_t t1) -> float {
+        const float b0 = __builtin_bit_cast(float, t0), b1 = __builtin_bit_cast(float, t1);
+        return __builtin_fmaf(b1, wxs, b0 * w0s);
+    };
+#else
     auto xlerp = [&](uint32_t t0, uint32_t t1) -> float {
         const float b0 = __builtin_bit_cast(float, t0), b1 = __builtin_bit_cast(float, t1);
         return __builtin_fmaf(b1 - b0, wxs, b0 * 0x1p127f);
     };
+#endif
     const float c00 = xlerp(t[0], t[1]), c10 = xlerp(t[2], t[3]), c01 = xlerp(t[4], t[5]), c11 = xlerp(t[6], t[7]);
     const float c0 = __builtin_fmaf(wy, c10 - c00, c00);
     const float c1 = __builtin_fmaf(wy, c11 - c01, c01);
     const float a22 = __builtin_fmaf(wz, c1 - c0, c0);
     if (a_out) *a_out = a22;
-    const float alpha_src = 1.0f - __builtin_amdgcn_exp2f(a22 * kexp22);
-    const float om = 1.0f - acc.alpha;
-    const float wgt = om * alpha_src;
+    const float e = __builtin_amdgcn_exp2f(a22 * kexp22);
+    const float alpha_src = 1.0f - e;
+    constexpr bool TR = !ERT && VRM_TRANSMITTANCE != 0; // (see shade())
+    const float om = TR ? acc.alpha : 1.0f - acc.alpha;
+    const float t1 = om * e;
+    const float wgt = TR ? om - t1 : om * alpha_src;
     if (USE_TF) tf_blend(a22, wgt, P, acc);
     else acc.cr = __builtin_fmaf(wgt, a22, acc.cr); // r == g == b == a for scalar volumes (finish_colour() rescales)
-    acc.alpha = __builtin_fmaf(om, alpha_src, acc.alpha);
+    acc.alpha = TR ? t1 : __builtin_fmaf(om, alpha_src, acc.alpha);
     return ERT ? acc.alpha >= 1.0f : false;
 }
 
-template <bool ALPHA_ONLY, bool USE_TF>
+template <bool ALPHA_ONLY, bool USE_TF, bool ERT>
 __device__ __forceinline__ void finish_colour(Accum &acc)
 {
+    if (!ERT && VRM_TRANSMITTANCE != 0) acc.alpha = 1.0f - acc.alpha; // the march carried the transmittance (see shade())
     if (!USE_TF) {
         const float s = T22 * (1.0f / 255.0f); // colours were accumulated in units of 2^-22 texel levels
         acc.cr *= s;
@@ -410,7 +440,7 @@ __global__ void __launch_bounds__(256) march_linear_kernel(const VrmMarchParams 
             dt += VRM_STEP_SIZE;          // wgsl:181, running f32 sum
             if (dt >= ray.t_max) break;   // wgsl:184-186
         }
-        finish_colour<ALPHA_ONLY, USE_TF>(acc);
+        finish_colour<ALPHA_ONLY, USE_TF, true>(acc);
     }
     store_pixel<DIAG>(v, P, px, py, acc, ray, iters, n_inside, n_inside);
 }
@@ -630,7 +660,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         ray[r] = setup_ray(v, g, in_image[r] ? px[r] : 0u, in_image[r] ? py : 0u, P.width, P.height);
-        acc[r] = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc[r] = {0.0f, 0.0f, 0.0f, !ERT && VRM_TRANSMITTANCE != 0 ? 1.0f : 0.0f};
         iters[r] = n_inside[r] = n_exec[r] = 0;
         active[r] = in_image[r] && ray[r].hit;
         dt[r] = ray[r].t_min;
@@ -643,7 +673,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     if (__builtin_amdgcn_ballot_w64(any_active) == 0ull) { // the tile misses the volume (half the tiles of a sphere view): clear colour
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            finish_colour<ALPHA_ONLY, USE_TF>(acc[r]);
+            finish_colour<ALPHA_ONLY, USE_TF, ERT>(acc[r]);
             if (in_image[r]) store_pixel<DIAG>(v, P, px[r], py, acc[r], ray[r], 0u, 0u, 0u);
         }
         return;
@@ -1324,9 +1354,17 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
                         const float u0 = uu[0], u1 = uu[1], u2 = uu[2];
                         const float f0 = floorf(u0), f1 = floorf(u1), f2 = floorf(u2);
                         uint32_t c[8];
-                        if (PACKED) fetch_global_alpha(g, (int)f0, (int)f1, (int)f2, c); // (the alpha byte is all the 1-channel filter reads)
-                        else fetch_global(g, (int)f0, (int)f1, (int)f2, c);
-                        done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r]);
+                        if constexpr (PACKED) {
+                            // the alpha byte is all the 1-channel filter reads -- through the SAME filter as the staged samples
+                            // (shade_bytes): what a sample contributes must not depend on which path a chunking sends it down
+                            fetch_global_alpha(g, (int)f0, (int)f1, (int)f2, c);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) c[k] >>= 24;
+                            done = shade_bytes<USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r]);
+                        } else {
+                            fetch_global(g, (int)f0, (int)f1, (int)f2, c);
+                            done = shade<ALPHA_ONLY, USE_TF, ERT>(c, u0 - f0, u1 - f1, u2 - f2, kexp, tf, acc[r]);
+                        }
                     }
                     // (a ray that stopped keeps no use for dt: the sum may advance unconditionally)
                     dt[r] += VRM_STEP_SIZE;
@@ -1343,7 +1381,7 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
     unsigned long long n_exec_lane = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        finish_colour<ALPHA_ONLY, USE_TF>(acc[r]);
+        finish_colour<ALPHA_ONLY, USE_TF, ERT>(acc[r]);
         if (in_image[r]) store_pixel<DIAG>(v, P, px[r], py, acc[r], ray[r], iters[r], n_inside[r], n_exec[r]);
         n_exec_lane += n_exec[r];
     }
