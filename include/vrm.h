@@ -99,7 +99,9 @@ VRM_API int vrm_draw_batch(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
  * descriptors (inverse view-projection, position, output pointers; 120 B per view) -- lives: in a file-scope device array
  * of the library (30 KiB per GPU, held until the process ends) instead of the ring vrm_create allocated.  The call itself
  * performs no hipMalloc / hipFree / event creation and no host allocation.  Limits: n <= 256 views per call (larger batches
- * are VRM_ERR_INVALID; split them); VRM_OPT_DIAGNOSTICS and VRM_OPT_PROFILE are ignored (both allocate).  Every call on a
+ * are VRM_ERR_INVALID; split them); VRM_OPT_DIAGNOSTICS and VRM_OPT_PROFILE are ignored (both allocate); VRM_ERR_STATE for a
+ * volume whose RGBA copies this draw needs and are not there (a compact scalar volume with RGBA-staging kernel options, or a
+ * grid that was resized and not yet uploaded to or drawn: vrm_draw_batch materialises those).  Every call on a
  * GPU shares that GPU's array: calls are stream-ordered within one context, but calls from DIFFERENT contexts on the same
  * GPU that overlap in time race on it -- serialise them (vrm_synchronize) or use vrm_draw_batch. */
 VRM_API int vrm_draw_batch_static(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint32_t n, vrm_image *const *targets);
@@ -111,7 +113,10 @@ VRM_API int vrm_synchronize(vrm_ctx *ctx);
 
 /* VoxelGrid::new (voxel/grid.rs:44-200) as the loaders call it (dat.rs:57, netcdf.rs:47): new
  * X*Y*Z grid of default voxels; attenuation resets to 1.0 (grid.rs:100,197); the transfer-function
- * struct resets to its defaults (grid.rs:198). */
+ * struct resets to its defaults (grid.rs:198).  The default voxels [0,0,0,255] are a promise: every loader overwrites them
+ * at once (dat.rs:21, netcdf.rs:47), so the call allocates about 1 B/voxel and the 8 B/voxel of RGBA storage with the fill
+ * come when something looks at the grid before an upload has replaced it (a draw, a download) -- a scalar upload
+ * (vrm_grid_upload_scalar) then never allocates them.  The 3x3x3 grid vrm_create makes is filled at once. */
 VRM_API int vrm_grid_resize(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z);
 
 /* set_color over the whole grid + update_buffer (grid.rs:202-238, Texture3D::from_image
@@ -126,7 +131,9 @@ VRM_API int vrm_grid_upload_f32(vrm_ctx *ctx, const float *host_czyx, uint32_t c
 VRM_API int vrm_grid_upload_f32_device(vrm_ctx *ctx, const void *device_czyx, uint32_t channels);
 
 /* loaders/dat.rs:58-76 quantisation: raw UCHAR (bytes_per_sample 1) or USHORT combined big-endian
- * (bytes_per_sample 2); voxel = [b,b,b,b]. */
+ * (bytes_per_sample 2); voxel = [b,b,b,b].  With the default options (VRM_OPT_COMPACT_SCALAR, the packed march) the packed
+ * alpha bricks and the occupancy pyramid are built straight from the raw samples: the ingest peaks at the raw samples
+ * + 1 B/voxel on the device, never the 9 B/voxel of the RGBA form. */
 VRM_API int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, size_t nbytes, uint32_t bytes_per_sample);
 
 /* Index<UVec3> over the whole grid (grid.rs:249-263): copies the RGBA8 voxels back, x fastest. */

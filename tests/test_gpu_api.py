@@ -455,7 +455,16 @@ def test_scalar_volume_is_held_compact_and_expands_on_demand(vr, orc):
 
     r = vr.RayMarcher(0, R, R)
     r.voxel_grid.new(dims)
-    assert r.voxel_grid.resident_bytes() >= 9 * n                   # default voxels [0,0,0,255] are not scalar
+    # a grid that was resized and not yet filled holds its default voxels [0,0,0,255] as a promise: the 8 B/voxel of RGBA
+    # storage come when something looks at it ...
+    assert r.voxel_grid.resident_bytes() < 2.2 * n
+    default = render(r)
+    dvox = np.zeros(dims[::-1] + (4,), np.uint8)
+    dvox[..., 3] = 255
+    assert image_metrics(default[0], orc.render(dvox, sphere_cam(orc, 1, 3), R, R, want_f32=False)["rgba8"])["max"] <= 1
+    assert default[0][..., 3].max() > 100 and r.voxel_grid.resident_bytes() >= 9 * n
+    assert np.array_equal(r.voxel_grid.download_rgba8(), dvox)
+    # ... and a scalar upload (direct ingest: packed bricks and pyramid straight from the raw samples) releases them again
     r.voxel_grid.upload_scalar(dens.reshape(-1), dims, 1)
     compact = r.voxel_grid.resident_bytes()
     assert compact < 2.2 * n, (compact, n)                           # packed bricks (padded to 16 x 4 x 2) + pyramid
@@ -525,3 +534,50 @@ def test_comm_broadcast_two_ranks(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     h = [(tmp_path / f"out{r}").read_text() for r in range(2)]
     assert h[0] == h[1] and len(h[0]) == 64                       # same voxels downloaded, same image rendered on both ranks
+
+
+def test_direct_scalar_ingest_equals_the_long_way_round(vr, orc):
+    """vrm_grid_upload_scalar with the default options builds the packed alpha bricks and the occupancy pyramid straight from
+    the raw samples (UCHAR and big-endian USHORT, dat.rs:62-74) and never allocates the RGBA form: the voxels that come back
+    (vrm_grid_download_rgba8 expands the bricks) and the images must equal those of the upload that quantises to RGBA8 first
+    (VRM_OPT_COMPACT_SCALAR = 0), and the oracle's quantisation.  Dims off every brick boundary; a fresh context whose grid was
+    never materialised, and a context that held another volume before."""
+    R = 80
+    cam = sphere_cam(orc, 2, 5)
+    for dims, bps in [((45, 38, 51), 1), ((33, 17, 9), 2), ((16, 4, 2), 2), ((1, 1, 1), 1)]:
+        n = dims[0] * dims[1] * dims[2]
+        rng = np.random.default_rng(n + bps)
+        if bps == 1:
+            raw = synth.blobs_scalar_u8(dims).reshape(-1) if min(dims) >= 8 else rng.integers(0, 256, n, dtype=np.uint8)
+            want = raw.reshape(dims[::-1])
+        else:
+            v16 = rng.integers(0, 65536, n, dtype=np.uint16)
+            v16[: n // 3] = 0                                         # empty space for the pyramid
+            raw = v16.astype(">u2").view(np.uint8)
+            want = ((v16.astype(np.float32) / np.float32(65535.0)) * np.float32(255.0)).astype(np.uint8).reshape(dims[::-1])
+        out = {}
+        for compact in (1, 0):
+            r = vr.RayMarcher(0, R, R)
+            r.set_option(vr.OPT_COMPACT_SCALAR, compact)
+            if compact:                                               # a context that held something else before
+                r.voxel_grid.new((7, 5, 3))
+                r.voxel_grid.upload_rgba8(synth.random_rgba8((7, 5, 3), 1))
+            r.voxel_grid.new(dims)
+            r.voxel_grid.upload_scalar(raw, dims, bps)
+            if compact:
+                assert r.voxel_grid.resident_bytes() < 2.2 * n + 4096
+            r.voxel_grid.attenuation = 6.0
+            r.voxel_grid.update_voxel_grid_buffer()
+            img = vr.Screenshotter(r, R, R)
+            outs = []
+            for skip in (1, 0):
+                r.set_option(vr.OPT_SKIP_EMPTY, skip)
+                r.draw(vr.uniform_from_array(cam), img)
+                outs.append(img.read())
+            assert np.array_equal(outs[0], outs[1])                   # the pyramid built from the raw samples is exact
+            vox = r.voxel_grid.download_rgba8()
+            img.close()
+            r.close()
+            out[compact] = (outs[0], vox)
+        assert np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][0], out[0][0])
+        assert np.array_equal(out[1][1], np.repeat(want[..., None], 4, axis=3))

@@ -2,7 +2,8 @@
 """The WHOLE C5 volume (2048 x 2048 x 4096 scalar, 16 GiB of u8 -- 64 GiB as the f32 BASELINE.json names, beyond the reference's
 4096-per-axis 3-D texture limit, state.rs:59) on ONE MI355X, unpartitioned: since round 3 a scalar volume is held compact
 (packed alpha bricks + occupancy pyramid, about 1.1 B/voxel), so the 17.2 G voxels need 19 GB of the 288 GB once ingested
-(the ingest itself passes through the 9 B/voxel form: 155 GB).  Renders a few 2048^2 views, checks skipping on/off
+(the ingest builds that form straight from the raw samples: raw staging + 1 B/voxel, 35 GB; it passed through the 9 B/voxel
+RGBA form, 155 GB, before the direct ingest).  Renders a few 2048^2 views, checks skipping on/off
 bit-identical and a crop of each against the oracle (orc_render_slab_stored over all slices, from the u8 volume on the host).
     python tools/c5_whole.py [--dims X Y Z] [--res R] [--views N] [--json out.json]"""
 import argparse
@@ -35,12 +36,12 @@ def main():
     r = vr.RayMarcher(0, R, R)
     t0 = time.time()
     r.voxel_grid.new(dims)
-    peak = r.voxel_grid.resident_bytes()
+    peak = r.voxel_grid.resident_bytes() + vol.nbytes   # the grid as the upload finds it + the raw samples staged on the device
     r.voxel_grid.upload_scalar(vol.reshape(-1), dims, 1)
     r.synchronize()
     ingest_s = time.time() - t0
     resident = r.voxel_grid.resident_bytes()
-    print(f"ingested in {ingest_s:.1f} s; the grid held {peak / 1e9:.1f} GB during the ingest, holds {resident / 1e9:.2f} GB now "
+    print(f"ingested in {ingest_s:.1f} s; grid + staged raw samples were {peak / 1e9:.1f} GB during the ingest, the grid holds {resident / 1e9:.2f} GB now "
           f"({resident / vol.nbytes:.2f} B/voxel)", flush=True)
     views = oracle.sphere_views(8, 5)
     picks = [views[i] for i in np.linspace(0, len(views) - 1, a.views).astype(int)]

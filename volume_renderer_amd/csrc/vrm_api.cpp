@@ -121,24 +121,47 @@ static int grid_rgba_storage(vrm_ctx *ctx)
 
 static int grid_expand(vrm_ctx *ctx)
 {
-    if (ctx->vox && ctx->bricks) return VRM_OK;
+    if (ctx->vox && ctx->bricks && !ctx->lazy_default) return VRM_OK;
     REQUIRE(ctx->abricks != nullptr, "the context holds no voxel grid");
     const bool had_vox = ctx->vox != nullptr;
     int rc = grid_rgba_storage(ctx);
     if (rc) return rc;
+    if (ctx->lazy_default) {
+        // a grid that was resized and never filled: now somebody looks at it -- Voxel::default = [0,0,0,255] (voxel.rs:13-16)
+        HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
+        HIP_TRY(vrm_launch_build_occupancy(ctx->vox, 0, ctx->dim, ctx->occ, ctx->stream));
+        HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
+        HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, 0, ctx->dim, ctx->abricks, ctx->stream));
+        ctx->lazy_default = false;
+        return VRM_OK;
+    }
     if (!had_vox) HIP_TRY(vrm_launch_expand_alpha_bricks(ctx->abricks, ctx->dim, ctx->vox, ctx->stream));
     HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
     return VRM_OK;
 }
 
-int vrm_grid_expand_internal(vrm_ctx *ctx) { return grid_expand(ctx); }
 
 // does the march, as the options stand, read anything but the packed alpha bricks and the pyramid?
-static bool draw_needs_rgba(const vrm_ctx *ctx)
+static bool march_needs_rgba(const vrm_ctx *ctx, bool scalar)
 {
-    const bool one_channel = ctx->scalar || ctx->tf.use_transfer_function[0] != 0;
+    const bool one_channel = scalar || ctx->tf.use_transfer_function[0] != 0;
     return !(one_channel && ctx->opt_packed != 0 && (ctx->opt_kernel == 1 || ctx->opt_kernel == 3 || ctx->opt_kernel == 4));
 }
+static bool draw_needs_rgba(const vrm_ctx *ctx) { return march_needs_rgba(ctx, ctx->scalar); }
+
+// what every consumer of the volume calls first: a grid that was resized and never filled gets its default contents now, and
+// a compact scalar volume its RGBA copies if `need_rgba` (or the options of the march) ask for them
+static int grid_ready(vrm_ctx *ctx, bool need_rgba)
+{
+    if (!ctx->abricks) {
+        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
+        return VRM_ERR_STATE;
+    }
+    if (ctx->lazy_default || ((!ctx->vox || !ctx->bricks) && (need_rgba || draw_needs_rgba(ctx)))) return grid_expand(ctx);
+    return VRM_OK;
+}
+
+int vrm_grid_expand_internal(vrm_ctx *ctx) { return grid_ready(ctx, true); }
 
 static int grid_compact(vrm_ctx *ctx)
 {
@@ -155,10 +178,9 @@ static int grid_alloc_buffers(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
 {
     const size_t words = (size_t)x * y * z;
     const uint32_t xyz[3] = {x, y, z};
-    HIP_TRY(hipMalloc((void **)&ctx->vox, words * 4));
+    // (the x-fastest RGBA8 copy and the RGBA bricks, 8 B/voxel, are allocated by whoever first needs them: grid_rgba_storage)
     uint32_t occ_off[VRM_OCC_LEVELS];
     HIP_TRY(hipMalloc((void **)&ctx->occ, vrm_occupancy_bytes(xyz, occ_off)));
-    HIP_TRY(hipMalloc((void **)&ctx->bricks, rgba_bricks_bytes(xyz)));
     HIP_TRY(hipMalloc((void **)&ctx->abricks, vrm_alpha_bricks_bytes(xyz)));
     ctx->vox_words = words;
     ctx->dim[0] = x; ctx->dim[1] = y; ctx->dim[2] = z;
@@ -198,11 +220,10 @@ static int grid_alloc(vrm_ctx *ctx, uint32_t x, uint32_t y, uint32_t z)
 
 static int grid_reset_contents(vrm_ctx *ctx)
 {
-    // Voxel::default = [0,0,0,255] (voxel.rs:13-16)
-    HIP_TRY(vrm_launch_fill(ctx->vox, ctx->vox_words, 0xFF000000u, ctx->stream));
-    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
-    HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
-    HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, ctx->dim, ctx->abricks, ctx->stream));
+    // Voxel::default = [0,0,0,255] (voxel.rs:13-16) -- as a promise: VoxelGrid::new is always followed by a loader that
+    // overwrites every voxel (dat.rs:21, netcdf.rs:47), so the fill and its 8 B/voxel of RGBA storage wait until something
+    // looks at the grid before an upload has replaced it (grid_expand); a scalar upload then never holds the RGBA form at all
+    ctx->lazy_default = true;
     ctx->scalar = false;
     ctx->attenuation = 1.0f;   // grid.rs:100,197
     tf_defaults(&ctx->tf);     // grid.rs:198
@@ -291,6 +312,7 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
             break;
         ctx->views_cap = 0; // ring write position
         if ((rc = vrm_grid_resize(ctx, 3, 3, 3))) break; // ray_marcher/mod.rs:29
+        if ((rc = grid_expand(ctx))) break; // (the start-up grid is materialised at once: a fresh context can be drawn by the entry point that may not allocate)
     } while (0);
     if (rc) {
         vrm_destroy(ctx);
@@ -331,9 +353,10 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
 // after new voxel data: is the volume scalar (r == g == b == a)?  (selects the 1-channel filter)
 static int grid_finish_upload(vrm_ctx *ctx)
 {
-    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, ctx->dim, ctx->occ, ctx->stream));
+    ctx->lazy_default = false; // (every voxel has just been written)
+    HIP_TRY(vrm_launch_build_occupancy(ctx->vox, 0, ctx->dim, ctx->occ, ctx->stream));
     HIP_TRY(vrm_launch_build_bricks(ctx->vox, ctx->dim, ctx->bricks, ctx->stream));
-    HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, ctx->dim, ctx->abricks, ctx->stream));
+    HIP_TRY(vrm_launch_build_alpha_bricks(ctx->vox, 0, ctx->dim, ctx->abricks, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->flag_dev, 0, 4, ctx->stream));
     HIP_TRY(vrm_launch_detect_nonscalar(ctx->vox, ctx->vox_words, ctx->flag_dev, ctx->stream));
     uint32_t flag = 1;
@@ -405,11 +428,33 @@ extern "C" int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, siz
     REQUIRE(bytes_per_sample == 1 || bytes_per_sample == 2, "bytes_per_sample must be 1 (UCHAR) or 2 (USHORT)");
     REQUIRE(nbytes == ctx->vox_words * bytes_per_sample, "expected %zu bytes, got %zu", ctx->vox_words * bytes_per_sample, nbytes);
     uint8_t *tmp = nullptr;
+    // Direct ingest: a DAT volume is scalar by construction (dat.rs:74 writes the one value to all four channels), and
+    // with the default options the march reads only its packed alpha bricks and the pyramid -- so both are built straight
+    // from the raw samples and the 8 B/voxel of RGBA copies are never allocated: the ingest peaks at the raw samples plus
+    // 1 B/voxel instead of 9 B/voxel (what lets a 2048 x 2048 x 4096 volume in at 35 GB instead of 155).  Same bytes as
+    // the long way round (tests/test_gpu_api.py).
+    const bool direct = ctx->opt_compact != 0 && !march_needs_rgba(ctx, true);
+    if (direct) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // draws in flight may still read the copies released here
+        if (ctx->vox) (void)hipFree(ctx->vox);
+        if (ctx->bricks) (void)hipFree(ctx->bricks);
+        ctx->vox = nullptr;
+        ctx->bricks = nullptr;
+    }
     HIP_TRY(hipMalloc((void **)&tmp, nbytes));
     rc = vrm_check_hip(hipMemcpyAsync(tmp, host_raw, nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-    if (!rc) rc = grid_rgba_storage(ctx);
-    if (!rc) rc = vrm_check_hip(vrm_launch_quantize_scalar(tmp, bytes_per_sample, ctx->vox_words, ctx->vox, ctx->stream), "quantize");
-    if (!rc) rc = grid_finish_upload(ctx);
+    if (direct) {
+        if (!rc) rc = vrm_check_hip(vrm_launch_build_occupancy(tmp, bytes_per_sample, ctx->dim, ctx->occ, ctx->stream), "occupancy");
+        if (!rc) rc = vrm_check_hip(vrm_launch_build_alpha_bricks(tmp, bytes_per_sample, ctx->dim, ctx->abricks, ctx->stream), "alpha bricks");
+        if (!rc) {
+            ctx->lazy_default = false;
+            ctx->scalar = true;
+        }
+    } else {
+        if (!rc) rc = grid_rgba_storage(ctx);
+        if (!rc) rc = vrm_check_hip(vrm_launch_quantize_scalar(tmp, bytes_per_sample, ctx->vox_words, ctx->vox, ctx->stream), "quantize");
+        if (!rc) rc = grid_finish_upload(ctx);
+    }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(tmp);
     return rc;
@@ -421,7 +466,7 @@ extern "C" int vrm_grid_download_rgba8(vrm_ctx *ctx, uint8_t *host_voxels, size_
     if (rc) return rc;
     REQUIRE(host_voxels != nullptr, "null voxel pointer");
     REQUIRE(nbytes == ctx->vox_words * 4, "expected %zu bytes (4*X*Y*Z), got %zu", ctx->vox_words * 4, nbytes);
-    if ((rc = grid_expand(ctx))) return rc; // a compact scalar volume: [b,b,b,b] back from the packed alpha bricks
+    if ((rc = grid_ready(ctx, true))) return rc; // a compact scalar volume: [b,b,b,b] back from the packed alpha bricks
     HIP_TRY(hipMemcpyAsync(host_voxels, ctx->vox, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VRM_OK;
@@ -774,11 +819,13 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
         vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
         return VRM_ERR_STATE;
     }
-    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx)) {
-        // a compact scalar volume and options that stage RGBA texels (VRM_OPT_KERNEL 0 / 2, VRM_OPT_PACKED_ALPHA 0): expand it
+    if (ctx->lazy_default || ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx))) {
+        // a grid nobody has filled yet, or a compact scalar volume and options that stage RGBA texels (VRM_OPT_KERNEL 0 / 2,
+        // VRM_OPT_PACKED_ALPHA 0): materialise / expand it
         if (use_static) {
-            vrm_set_error("vrm_draw_batch_static: the scalar volume is held in its compact form and these options need the RGBA copies, "
-                          "which this entry point may not allocate (draw once with vrm_draw_batch, or keep the default kernel options)");
+            vrm_set_error("vrm_draw_batch_static: the volume is held in a compact form (a scalar volume, or a grid that was resized and "
+                          "never filled) and this draw needs its RGBA copies, which this entry point may not allocate (draw once with "
+                          "vrm_draw_batch, or keep the default kernel options)");
             return VRM_ERR_STATE;
         }
         if ((rc = grid_expand(ctx))) return rc;
@@ -886,11 +933,7 @@ extern "C" int vrm_draw_partial(vrm_ctx *ctx, const vrm_camera_uniform *cameras,
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (!ctx->abricks) {
-        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
-        return VRM_ERR_STATE;
-    }
-    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx) && (rc = grid_expand(ctx))) return rc;
+    if ((rc = grid_ready(ctx, false))) return rc;
     REQUIRE(cameras != nullptr && rgba_f32_device != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
@@ -941,11 +984,7 @@ extern "C" int vrm_count_reference_samples(vrm_ctx *ctx, const vrm_camera_unifor
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (!ctx->abricks) {
-        vrm_set_error("the context holds no voxel grid (an earlier vrm_grid_resize failed)");
-        return VRM_ERR_STATE;
-    }
-    if ((!ctx->vox || !ctx->bricks) && draw_needs_rgba(ctx) && (rc = grid_expand(ctx))) return rc;
+    if ((rc = grid_ready(ctx, false))) return rc;
     REQUIRE(cameras != nullptr && out_total != nullptr, "null argument");
     REQUIRE(n > 0 && n <= kViewRing && n <= 65535, "batch size %u out of range (1..%u)", n, kViewRing);
     REQUIRE(width > 0 && height > 0 && width <= 65536 && height <= 65536, "bad image size %u x %u", width, height);
@@ -1103,7 +1142,7 @@ extern "C" int vrm_grid_broadcast(vrm_ctx *ctx, int root)
     }
     REQUIRE(root >= 0 && root < ctx->comm_size, "root %d outside the %d ranks", root, ctx->comm_size);
     REQUIRE(ctx->abricks != nullptr && ctx->vox_words != 0, "no grid");
-    if ((rc = grid_expand(ctx))) return rc; // (what travels is the RGBA8 form every rank ingests)
+    if ((rc = grid_ready(ctx, true))) return rc; // (what travels is the RGBA8 form every rank ingests)
     REQUIRE(ctx->gdim[2] == ctx->dim[2], "a slab-partitioned grid is not replicated: nothing to broadcast");
     // every rank must hold a grid of the same dimensions (vrm_grid_resize); the root's voxels replace the others' in place
     const int e = rccl().Broadcast(ctx->vox, ctx->vox, ctx->vox_words * 4, /* ncclUint8 */ 1, root, ctx->comm, ctx->stream);

@@ -92,11 +92,13 @@ hipError_t vrm_launch_march(const VrmMarchParams &p, uint32_t n_views, int varia
                             hipStream_t stream);
 // bytes of the occupancy pyramid of a dim[0] x dim[1] x dim[2] volume; off[L] = byte offset of level L
 size_t vrm_occupancy_bytes(const uint32_t dim[3], uint32_t off[VRM_OCC_LEVELS]);
-hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream);
+// `src` and `bps` of the two builders below: the x-fastest RGBA8 words (bps 0), or the raw samples of a scalar volume (bps 1:
+// UCHAR, 2: USHORT big-endian) quantised on the fly as dat.rs does -- the direct ingest that never holds the RGBA form
+hipError_t vrm_launch_build_occupancy(const void *src, uint32_t bps, const uint32_t dim[3], uint8_t *occ, hipStream_t stream);
 hipError_t vrm_launch_build_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *bricks, hipStream_t stream);
 // bytes of the packed alpha bricks of a dim[0] x dim[1] x dim[2] volume, and their builder
 size_t vrm_alpha_bricks_bytes(const uint32_t dim[3]);
-hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream);
+hipError_t vrm_launch_build_alpha_bricks(const void *src, uint32_t bps, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream);
 // a scalar volume's x-fastest RGBA8 voxels ([b,b,b,b]) back from its packed alpha bricks
 hipError_t vrm_launch_expand_alpha_bricks(const uint32_t *abricks, const uint32_t dim[3], uint32_t *vox, hipStream_t stream);
 hipError_t vrm_launch_count_samples(const VrmMarchParams &p, uint32_t n_views, unsigned long long *total_dev, hipStream_t stream);

@@ -23,6 +23,9 @@ struct vrm_ctx {
     uint32_t *vox = nullptr; // RGBA8 words, x fastest (nullptr, like `bricks`, while a scalar volume is held compact: vrm_api.cpp grid_compact)
     size_t vox_words = 0;
     bool scalar = false;     // r == g == b == a everywhere
+    // the grid was resized and nothing has been uploaded yet: its contents are Voxel::default by promise -- `vox` and `bricks`
+    // are not allocated, `abricks` and `occ` not filled -- until something looks at it (vrm_api.cpp grid_expand)
+    bool lazy_default = false;
     uint8_t *occ = nullptr;  // max alpha per 4x4x4-texel cell, rebuilt whenever the voxels change
     uint32_t *bricks = nullptr; // the same voxels in 4x4x2-texel bricks of one 128-byte line each (staging source)
     uint32_t *abricks = nullptr; // the alpha channel alone, 4 texels per word, bricked (1-channel march staging source)

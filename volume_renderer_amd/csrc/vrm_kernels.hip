@@ -1532,29 +1532,43 @@ __global__ void __launch_bounds__(256) quantize_f32_kernel(const float *__restri
     }
 }
 
-// loaders/dat.rs:62-74: big-endian combine, ((val / (2^(8n)-1)) * 255) as u8, replicated to RGBA
+// loaders/dat.rs:62-74: big-endian combine, ((val / (2^(8n)-1)) * 255) as u8 (replicated to RGBA by the caller)
+__device__ __forceinline__ uint32_t quantize_scalar(const uint8_t *__restrict__ raw, uint32_t bps, size_t i)
+{
+    float val, denom;
+    if (bps == 2) {
+        val = (float)(((uint32_t)raw[2 * i] << 8) | raw[2 * i + 1]);
+        denom = 65535.0f;
+    } else {
+        val = (float)raw[i];
+        denom = 255.0f;
+    }
+    float q = (val / denom) * 255.0f;
+    q = fminf(fmaxf(q, 0.0f), 255.0f);
+    return (uint32_t)q;
+}
+
 __global__ void __launch_bounds__(256) quantize_scalar_kernel(const uint8_t *__restrict__ raw, uint32_t bps, size_t n,
                                                               uint32_t *__restrict__ dst)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float val, denom;
-        if (bps == 2) {
-            val = (float)(((uint32_t)raw[2 * i] << 8) | raw[2 * i + 1]);
-            denom = 65535.0f;
-        } else {
-            val = (float)raw[i];
-            denom = 255.0f;
-        }
-        float q = (val / denom) * 255.0f;
-        q = fminf(fmaxf(q, 0.0f), 255.0f);
-        dst[i] = (uint32_t)q * 0x01010101u;
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = quantize_scalar(raw, bps, i) * 0x01010101u;
+}
+
+// The alpha of voxel i as the two builders below read it: from the x-fastest RGBA8 words (BPS = 0), or straight from the raw
+// samples of a scalar volume (BPS = 1, 2: the direct ingest, which never holds the RGBA form -- the value every channel of
+// that voxel would get, quantised as dat.rs does).
+template <int BPS>
+__device__ __forceinline__ uint32_t source_alpha(const void *__restrict__ src, size_t i)
+{
+    if constexpr (BPS == 0) return static_cast<const uint32_t *>(src)[i] >> 24;
+    else return quantize_scalar(static_cast<const uint8_t *>(src), (uint32_t)BPS, i);
 }
 
 // max alpha of every 4x4x4-voxel cell: the look-up behind exact empty-space skipping.  One wave per 8x8x8-voxel
 // region = 2x2x2 cells; lane (lx, ly) walks z, then the 4x4 lanes of a cell column are reduced by xor shuffles.
-__global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
+template <int BPS>
+__global__ void __launch_bounds__(64) build_occupancy_kernel(const void *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
                                                              uint32_t rx_n, uint32_t ry_n, uint32_t ox_n, uint32_t oy_n,
                                                              uint32_t oz_n, uint8_t *__restrict__ occ)
 {
@@ -1566,7 +1580,7 @@ __global__ void __launch_bounds__(64) build_occupancy_kernel(const uint32_t *__r
     if (x < X && y < Y)
         for (uint32_t k = 0; k < 8u; ++k) {
             const uint32_t z = rz * 8u + k;
-            if (z < Z) m[k >> 2] = max(m[k >> 2], vox[((size_t)z * Y + y) * X + x] >> 24);
+            if (z < Z) m[k >> 2] = max(m[k >> 2], source_alpha<BPS>(vox, ((size_t)z * Y + y) * X + x));
         }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1623,7 +1637,8 @@ __global__ void __launch_bounds__(256) build_bricks_kernel(const uint32_t *__res
 
 // The alpha channel alone, bricked like `bricks` over words of four x-adjacent texels (VrmGridDev::abricks): one
 // 16-byte quad = 16 texels of one (y, z) row, edge-replicated past the volume.
-__global__ void __launch_bounds__(256) build_alpha_bricks_kernel(const uint32_t *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
+template <int BPS>
+__global__ void __launch_bounds__(256) build_alpha_bricks_kernel(const void *__restrict__ vox, uint32_t X, uint32_t Y, uint32_t Z,
                                                                  uint32_t nbxa, uint32_t nby, size_t n_quads,
                                                                  u32x4 *__restrict__ abricks)
 {
@@ -1634,14 +1649,14 @@ __global__ void __launch_bounds__(256) build_alpha_bricks_kernel(const uint32_t 
         const size_t bz = brick / ((size_t)nbxa * nby), r = brick - bz * nbxa * nby;
         const uint32_t by = (uint32_t)(r / nbxa), bx = (uint32_t)(r - (size_t)by * nbxa);
         const uint32_t y = min(by * 4u + (local & 3u), Y - 1u), z = min((uint32_t)bz * 2u + (local >> 2), Z - 1u);
-        const uint32_t *row = vox + ((size_t)z * Y + y) * X;
+        const size_t row = ((size_t)z * Y + y) * X;
         const uint32_t x = bx * 16u;
         uint32_t w[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
             w[q] = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) w[q] |= (row[min(x + 4u * q + k, X - 1u)] >> 24) << (8u * k);
+            for (uint32_t k = 0; k < 4u; ++k) w[q] |= source_alpha<BPS>(vox, row + min(x + 4u * q + k, X - 1u)) << (8u * k);
         }
         u32x4 o;
         o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
@@ -1943,12 +1958,15 @@ size_t vrm_alpha_bricks_bytes(const uint32_t dim[3])
     return (size_t)((dim[0] + 15) / 16) * ((dim[1] + 3) / 4) * ((dim[2] + 1) / 2) * 128;
 }
 
-hipError_t vrm_launch_build_alpha_bricks(const uint32_t *vox, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream)
+hipError_t vrm_launch_build_alpha_bricks(const void *src, uint32_t bps, const uint32_t dim[3], uint32_t *abricks, hipStream_t stream)
 {
     const uint32_t nbxa = (dim[0] + 15) / 16, nby = (dim[1] + 3) / 4, nbz = (dim[2] + 1) / 2;
     const size_t n_quads = (size_t)nbxa * nby * nbz * 8;
-    hipLaunchKernelGGL(build_alpha_bricks_kernel, dim3(stream_blocks(n_quads)), dim3(256), 0, stream, vox, dim[0], dim[1], dim[2], nbxa,
-                       nby, n_quads, reinterpret_cast<u32x4 *>(abricks));
+    const dim3 grid(stream_blocks(n_quads)), block(256);
+    u32x4 *out = reinterpret_cast<u32x4 *>(abricks);
+    if (bps == 0) hipLaunchKernelGGL(build_alpha_bricks_kernel<0>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], nbxa, nby, n_quads, out);
+    else if (bps == 1) hipLaunchKernelGGL(build_alpha_bricks_kernel<1>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], nbxa, nby, n_quads, out);
+    else hipLaunchKernelGGL(build_alpha_bricks_kernel<2>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], nbxa, nby, n_quads, out);
     return hipGetLastError();
 }
 
@@ -1974,12 +1992,14 @@ size_t vrm_occupancy_bytes(const uint32_t dim[3], uint32_t off[VRM_OCC_LEVELS])
     return total;
 }
 
-hipError_t vrm_launch_build_occupancy(const uint32_t *vox, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
+hipError_t vrm_launch_build_occupancy(const void *src, uint32_t bps, const uint32_t dim[3], uint8_t *occ, hipStream_t stream)
 {
     const uint32_t rx = (dim[0] + 7) / 8, ry = (dim[1] + 7) / 8, rz = (dim[2] + 7) / 8;
     const uint32_t od[3] = {(dim[0] + 3) / 4, (dim[1] + 3) / 4, (dim[2] + 3) / 4};
-    hipLaunchKernelGGL(build_occupancy_kernel, dim3(rx * ry * rz), dim3(64), 0, stream, vox, dim[0], dim[1], dim[2], rx, ry, od[0], od[1],
-                       od[2], occ);
+    const dim3 grid(rx * ry * rz), block(64);
+    if (bps == 0) hipLaunchKernelGGL(build_occupancy_kernel<0>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], rx, ry, od[0], od[1], od[2], occ);
+    else if (bps == 1) hipLaunchKernelGGL(build_occupancy_kernel<1>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], rx, ry, od[0], od[1], od[2], occ);
+    else hipLaunchKernelGGL(build_occupancy_kernel<2>, grid, block, 0, stream, src, dim[0], dim[1], dim[2], rx, ry, od[0], od[1], od[2], occ);
     uint32_t off[VRM_OCC_LEVELS];
     (void)vrm_occupancy_bytes(dim, off);
     for (int l = 1; l < VRM_OCC_LEVELS && off[l] != 0; ++l) {
