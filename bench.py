@@ -301,7 +301,9 @@ def main():
     ap.add_argument("--radius", type=float, default=2.5)
     ap.add_argument("--attenuation", type=float, default=1.0)
     ap.add_argument("--tf", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=32, help="views per launch")
+    ap.add_argument("--batch", type=int, default=0, help="views per launch; 0 = automatic: 64 for images up to 1024^2 and at least 256 views per rank, else 32 "
+                    "(measured on C3, profiles/r3/batch_sweep.txt: 16 -> 3171, 32 -> 3315, 64 -> 3370, 128 -> 3306 views/s; "
+                    "larger launches have shorter tails, and the two banks of pinned images stay below 1 GiB)")
     ap.add_argument("--kernel", type=int, default=1, help="march kernel variant (0: global gathers, 1: LDS-staged)")
     ap.add_argument("--skip-empty", type=int, default=1, help="exact empty-space skipping (bit-identical image); "
                     "the no-skip rate is measured too and reported as views_per_s_no_skip")
@@ -409,7 +411,9 @@ def main():
     n_views = len(cams)
     mine = vd.partition_views(n_views, rank, world)
     my_cams = [cams[i] for i in mine]
-    B = max(1, min(a.batch, len(my_cams)))
+    # (64 only where that still leaves four launches to pipeline march and read-back: C2's 64 views in ONE launch of 64 ran at
+    # 8.2 k views/s against 13.1 k in two of 32)
+    B = max(1, min(a.batch if a.batch > 0 else (64 if R * R <= 1024 * 1024 and len(my_cams) >= 256 else 32), len(my_cams)))
     banks = [[vr.Screenshotter(rm, R, R) for _ in range(B)] for _ in range(2)]
 
     which = [0]                      # the banks alternate across steps too: with one launch per step (8 ranks x 32 views)
