@@ -82,6 +82,16 @@ def main():
             continue
         try:
             configure(rm, vox, att, tf)
+            if kind in ("scalar", "scalar_sparse") and case % 2 == 0:
+                # every other scalar case through the DAT path: vrm_grid_upload_scalar (the direct ingest when the options allow
+                # it: packed bricks and pyramid from the raw samples, no RGBA form)
+                g = rm.voxel_grid
+                g.new(dims)
+                g.upload_scalar(np.ascontiguousarray(vox[..., 3]).reshape(-1), dims, 1)
+                g.attenuation = att
+                g.update_voxel_grid_buffer()
+                g.set_transfer_function_active(tf)
+                g.update_transfer_function_buffer()
             got = draw(rm, vr, cam, W, H)
             if att < 600.0:
                 # f32 gate of the fuzz: 2e-4 (the deterministic test matrix holds 1e-4).  Two families of cases reach 1.1-1.2e-4:
