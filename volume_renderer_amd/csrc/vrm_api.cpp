@@ -1142,7 +1142,11 @@ extern "C" int vrm_grid_broadcast(vrm_ctx *ctx, int root)
     }
     REQUIRE(root >= 0 && root < ctx->comm_size, "root %d outside the %d ranks", root, ctx->comm_size);
     REQUIRE(ctx->abricks != nullptr && ctx->vox_words != 0, "no grid");
-    if ((rc = grid_ready(ctx, true))) return rc; // (what travels is the RGBA8 form every rank ingests)
+    // what travels is the RGBA8 form every rank ingests: the root needs its voxels there, a receiver only the storage (a grid it
+    // resized for this and never filled is not filled with default voxels first)
+    if (ctx->comm_rank != root && ctx->lazy_default) rc = grid_rgba_storage(ctx);
+    else rc = grid_ready(ctx, true);
+    if (rc) return rc;
     REQUIRE(ctx->gdim[2] == ctx->dim[2], "a slab-partitioned grid is not replicated: nothing to broadcast");
     // every rank must hold a grid of the same dimensions (vrm_grid_resize); the root's voxels replace the others' in place
     const int e = rccl().Broadcast(ctx->vox, ctx->vox, ctx->vox_words * 4, /* ncclUint8 */ 1, root, ctx->comm, ctx->stream);
