@@ -79,6 +79,20 @@ def test_static_draw_limits_and_errors(vr, orc):
     assert r.profile_read() == (0.0, 0)
     rc = _ffi.lib().vrm_draw_batch_static(r._h, None, 1, None)
     assert rc == _ffi.VRM_ERR_INVALID
+    # a grid that was resized and neither uploaded to nor drawn yet has no RGBA storage: the entry point that may not
+    # allocate says so (VRM_ERR_STATE), the allocating draw materialises the default voxels, and then it works
+    r.voxel_grid.new((9, 7, 5))
+    with pytest.raises(vr.VrmError) as e:
+        r.draw_batch_static([cam], imgs[:1])
+    assert e.value.status == _ffi.VRM_ERR_STATE and "may not allocate" in str(e.value)
+    r.draw_batch([cam], imgs[1:2])
+    r.draw_batch_static([cam], imgs[:1])
+    assert np.array_equal(imgs[0].read(), imgs[1].read()) and imgs[0].read()[..., 3].max() > 0
+    # a scalar upload leaves the compact form, which the default options march without anything else
+    r.voxel_grid.upload_scalar(np.full(9 * 7 * 5, 200, np.uint8), (9, 7, 5), 1)
+    r.draw_batch_static([cam], imgs[:1])
+    r.draw_batch([cam], imgs[1:2])
+    assert np.array_equal(imgs[0].read(), imgs[1].read())
     for im in imgs:
         im.close()
     r.close()
