@@ -306,6 +306,9 @@ extern "C" int vrm_create(const vrm_config *config, vrm_ctx **out_ctx)
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->flag_dev, 256), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipMemsetAsync(ctx->flag_dev, 0, 256, ctx->stream), "hipMemsetAsync"))) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->queue_dev, VRM_QUEUE_BYTES), "hipMalloc"))) break;
+        for (uint32_t i = 0; i < vrm_ctx::kBatchEvents && !rc; ++i)
+            rc = vrm_check_hip(hipEventCreateWithFlags(&ctx->batch_events[i], hipEventDisableTiming), "hipEventCreate");
+        if (rc) break;
         if ((rc = vrm_check_hip(hipMalloc((void **)&ctx->views_dev, sizeof(VrmViewDesc) * kViewRing), "hipMalloc"))) break;
         if ((rc = vrm_check_hip(hipHostMalloc((void **)&ctx->views_host, sizeof(VrmViewDesc) * kViewRing, hipHostMallocDefault),
                                 "hipHostMalloc")))
@@ -337,6 +340,8 @@ extern "C" void vrm_destroy(vrm_ctx *ctx)
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
+    for (hipEvent_t e : ctx->batch_events)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->vox) (void)hipFree(ctx->vox);
     if (ctx->occ) (void)hipFree(ctx->occ);
     if (ctx->bricks) (void)hipFree(ctx->bricks);
@@ -592,7 +597,7 @@ extern "C" int vrm_image_readback_async(vrm_image *img)
         return VRM_ERR_STATE;
     }
     vrm_ctx *ctx = img->ctx;
-    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, img->drawn, 0));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, img->drawn_batch ? img->drawn_batch : img->drawn, 0));
     HIP_TRY(hipMemcpyAsync(img->host, img->dev, img->pitch * img->height, hipMemcpyDeviceToHost, ctx->copy_stream));
     HIP_TRY(hipEventRecord(img->copied, ctx->copy_stream));
     img->copy_pending = true;
@@ -901,9 +906,12 @@ static int draw_batch_impl(vrm_ctx *ctx, const vrm_camera_uniform *cameras, uint
     }
     HIP_TRY(vrm_launch_march(p, n, (int)ctx->opt_kernel, diag, ctx->opt_skip != 0, ctx->stream));
     if (e1) HIP_TRY(hipEventRecord(e1, ctx->stream));
+    // one event behind the launch for all its targets (see vrm_image::drawn_batch)
+    hipEvent_t ev = ctx->batch_events[ctx->batch_next++ % vrm_ctx::kBatchEvents];
+    HIP_TRY(hipEventRecord(ev, ctx->stream));
     for (uint32_t i = 0; i < n; ++i) {
         vrm_image *img = targets[i];
-        HIP_TRY(hipEventRecord(img->drawn, ctx->stream));
+        img->drawn_batch = ev;
         img->has_draw = true;
         img->copy_valid = false;
         img->copy_pending = false;

@@ -54,6 +54,9 @@ struct vrm_ctx {
 
     // profiling (VRM_OPT_PROFILE)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    static constexpr uint32_t kBatchEvents = 64; // ring of per-launch "drawn" events, created with the context
+    hipEvent_t batch_events[kBatchEvents] = {};
+    uint32_t batch_next = 0;
     size_t prof_used = 0;
     double prof_ms = 0.0;
     uint64_t prof_launches = 0;
@@ -72,7 +75,11 @@ struct vrm_image {
     float *diag_rgba = nullptr;  // lazily allocated with VRM_OPT_DIAGNOSTICS
     uint32_t *diag_iters = nullptr;
     float *diag_geom = nullptr;
-    hipEvent_t drawn = nullptr;  // recorded on ctx->stream after the last draw into this image
+    hipEvent_t drawn = nullptr;  // recorded on ctx->stream when the image was created (its clear)
+    // the event behind the last draw into this image: ONE per launch, shared by the launch's targets, from the context's ring
+    // (an event per target and launch was 64 markers between two kernels: 0.3 ms of idle chip per launch).  A ring slot
+    // that has been re-recorded since stands for a LATER point of the same in-order stream: waiting on it is still enough.
+    hipEvent_t drawn_batch = nullptr;
     hipEvent_t copied = nullptr; // recorded on ctx->copy_stream after the last readback
     bool has_draw = false, copy_pending = false, copy_valid = false, mapped = false;
 };
