@@ -409,7 +409,7 @@ def main():
         csp.update_position(cam)
         cams.append(cam.uniform())
     n_views = len(cams)
-    mine = vd.partition_views(n_views, rank, world)
+    mine = vd.partition_views(n_views, rank, world, a.xdiv)
     my_cams = [cams[i] for i in mine]
     # (64 only where that still leaves four launches to pipeline march and read-back: C2's 64 views in ONE launch of 64 ran at
     # 8.2 k views/s against 13.1 k in two of 32)
@@ -527,7 +527,7 @@ def main():
         "ms_per_view": round(elapsed / a.steps / n_views * 1e3, 4),
         "ms_per_step_min": round(min(per_rank_ms), 3), "ms_per_step_max": round(max(per_rank_ms), 3),
         "per_rank": {"ms_per_step": [round(v, 3) for v in per_rank_ms], "kernel_ms_per_step": [round(v, 3) for v in per_rank_kernel_ms],
-                     "views": [len(vd.partition_views(n_views, r_, world)) for r_ in range(world)]},
+                     "views": [len(vd.partition_views(n_views, r_, world, a.xdiv)) for r_ in range(world)]},
         "volume_broadcast_ms": round(bcast_ms, 2),
         "volume_broadcast_gbs": round(D * D * D * 4 / (bcast_ms * 1e-3) / 1e9, 2) if bcast_ms > 0 else None,
         "rccl_ranks": 0 if (rehearse or world == 1) else world, "roofline": roofline,

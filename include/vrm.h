@@ -176,7 +176,9 @@ VRM_API int vrm_sphere_position(uint32_t ix, uint32_t iy, uint32_t x_div, uint32
 
 /* "Screenshot All" (sphere_screenshot_manager.rs:23-73, state.rs:318-322,391-397): renders the
  * x_div*(y_div-1) views (y outer from 1, x inner), writes `<out_dir>/<ix>-<iy>.png` and
- * `<out_dir>/cameras.json`.  Of that list this context renders views i with i % n_parts == part
+ * `<out_dir>/cameras.json`.  Of that list this context renders views i with (i + i / x_div) % n_parts == part -- interleaved, the interleave rotated by one from one
+ * row of the sphere to the next, so that a part does not get the same azimuths in every row (plain i % n_parts is 10 % out of
+ * balance at 8 parts of the 16-column export: the axis-aligned views are the cheap ones)
  * (view partitioning over GPUs/ranks); only part 0 writes cameras.json.  Uses ctx's default size. */
 VRM_API int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, float radius, const float origin[3],
                               const char *out_dir, uint32_t part, uint32_t n_parts);

@@ -22,6 +22,20 @@ def test_partition_is_an_interleaved_exact_cover():
         assert flat == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
         assert all(p == list(range(r, n, world)) for r, p in enumerate(parts))
+    # the export's form: the interleave rotated by one per row of x_div views -- still an exact cover, rows split evenly
+    # when world divides x_div, and no rank holds the same column in two consecutive rows
+    for n, world, x_div in [(256, 8, 16), (256, 4, 16), (56, 2, 8), (60, 3, 12), (20, 8, 5), (7, 2, 1)]:
+        parts = [vd.partition_views(n, r, world, x_div) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(n))
+        if x_div % world == 0 and n % x_div == 0:
+            assert len({len(p) for p in parts}) == 1
+        for r, p in enumerate(parts):
+            assert all((i + i // x_div) % world == r for i in p)
+            cols = {}
+            for i in p:
+                cols.setdefault(i // x_div, set()).add(i % x_div)
+            if world > 1 and x_div % world == 0:
+                assert all(not (cols[k] & cols[k + 1]) for k in cols if k + 1 in cols)
     with pytest.raises(ValueError):
         vd.partition_views(10, 2, 2)
 

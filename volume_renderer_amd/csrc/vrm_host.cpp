@@ -366,7 +366,7 @@ extern "C" int vrm_export_sphere(vrm_ctx *ctx, uint32_t x_div, uint32_t y_div, f
 
     std::vector<const View *> mine;
     for (size_t i = 0; i < all.size(); ++i)
-        if (i % n_parts == part) mine.push_back(&all[i]);
+        if ((i + i / x_div) % n_parts == part) mine.push_back(&all[i]); // interleaved, rotated by one per row of the sphere (see vrm.h)
     if (mine.empty()) return VRM_OK;
 
     const uint32_t bank = (uint32_t)std::min<size_t>(8, mine.size());

@@ -3,8 +3,8 @@ torch.distributed.run; torch.distributed (backend "nccl" = RCCL over xGMI on ROC
 for exactly three things: one broadcast of the volume, barriers, and a max-reduce of the timing.
 
 Views are independent (sphere_screenshot_manager.rs:33-54 carries no state between them), so the data
-path itself has no collective: rank r renders views {i : i % world == r} of the reference's view list and
-reads back its own images.
+path itself has no collective: rank r renders views {i : (i + i // x_div) % world == r} of the reference's view list --
+interleaved, the interleave rotated by one from one row of the sphere to the next -- and reads back its own images.
 """
 import os
 
@@ -14,12 +14,18 @@ def env_rank():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def partition_views(n_views, rank, world):
-    """interleaved view partition: balances the view-dependent cost (rays through the cube diagonal are
-    1.7x longer than axis-aligned ones) across ranks."""
+def partition_views(n_views, rank, world, x_div=None):
+    """Interleaved view partition: balances the view-dependent cost (rays through the cube diagonal are 1.7x longer than
+    axis-aligned ones) across ranks.  The view list is the sphere's rows of `x_div` azimuths each (y outer, x inner,
+    sphere_screenshot_manager.rs:23-54); a plain i % world gives a rank the SAME azimuths in every row whenever world divides
+    x_div -- 16 and 8: rank 0 renders only the axis-aligned columns; the slowest rank's share of the C3 export measured 5.8 %
+    above the mean at 8 and at 4 ranks (tools/partition_balance.py, profiles/r3/partition_balance.txt) -- so the interleave is
+    rotated by one per row: view i goes to rank (i + i // x_div) % world (0.3 % and 0.1 %).  Without x_div: plain interleave."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"bad rank/world {rank}/{world}")
-    return list(range(rank, n_views, world))
+    if not x_div:
+        return list(range(rank, n_views, world))
+    return [i for i in range(n_views) if (i + i // int(x_div)) % world == rank]
 
 
 def init_process_group(backend=None):
