@@ -1,5 +1,5 @@
 """Fixed cost of one march launch on C3: kernel time (hipEvents around the launch) of launches of 8 .. 128 views, a linear fit,
-and the diagnostics build's view of the same.    python tools/launch_overhead.py"""
+and the diagnostics build's view of the same.    python tools/launch_overhead.py [volume edge] [image edge]"""
 import os
 import sys
 
@@ -14,7 +14,8 @@ def main():
     import oracle
     import volume_renderer_amd as vr
     from volume_renderer_amd import synth
-    R, D = 1024, 512
+    R, D = (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), (int(sys.argv[1]) if len(sys.argv) > 1 else 512)
+    print(f"volume {D}^3, image {R}^2")
     rm = vr.RayMarcher(0, R, R)
     vol = torch.from_numpy(synth.quantize_rgba8(synth.blobs_rgba_f32((D, D, D)))).cuda()
     rm.voxel_grid.new((D, D, D))
@@ -23,7 +24,7 @@ def main():
     cams = [vr.uniform_from_array(oracle.camera_uniform(oracle.sphere_position(ix, iy, 16, 17, 2.5))) for ix, iy in views]
     imgs = [vr.Screenshotter(rm, R, R) for _ in range(128)]
     xs, ys = [], []
-    for kernel in (1, 4):
+    for kernel in (1,):
         rm.set_option(vr.OPT_KERNEL, kernel)
         for n in (8, 16, 32, 64, 128):
             tot, cnt = 0.0, 0

@@ -445,6 +445,10 @@ extern "C" int vrm_grid_upload_scalar(vrm_ctx *ctx, const uint8_t *host_raw, siz
         if (ctx->bricks) (void)hipFree(ctx->bricks);
         ctx->vox = nullptr;
         ctx->bricks = nullptr;
+        // (from here until the builders below have run the grid counts as never filled: should the staging buffer not fit, the
+        // context is left with default voxels, not with the packed bricks of a volume whose colours were just released)
+        ctx->lazy_default = true;
+        ctx->scalar = false;
     }
     HIP_TRY(hipMalloc((void **)&tmp, nbytes));
     rc = vrm_check_hip(hipMemcpyAsync(tmp, host_raw, nbytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
