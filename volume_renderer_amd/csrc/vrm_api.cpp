@@ -114,8 +114,20 @@ static size_t rgba_bricks_bytes(const uint32_t d[3]) { return (size_t)((d[0] + 3
 // storage for the 4 B/voxel copies (contents undefined): what every upload writes into
 static int grid_rgba_storage(vrm_ctx *ctx)
 {
+    // all or nothing: a `vox` without `bricks` left behind by a failed second allocation would later pass for a valid copy
+    const bool had_vox = ctx->vox != nullptr;
     if (!ctx->vox) HIP_TRY(hipMalloc((void **)&ctx->vox, ctx->vox_words * 4));
-    if (!ctx->bricks) HIP_TRY(hipMalloc((void **)&ctx->bricks, rgba_bricks_bytes(ctx->dim)));
+    if (!ctx->bricks) {
+        const int rc = vrm_check_hip(hipMalloc((void **)&ctx->bricks, rgba_bricks_bytes(ctx->dim)), "hipMalloc");
+        if (rc) {
+            ctx->bricks = nullptr;
+            if (!had_vox) {
+                (void)hipFree(ctx->vox);
+                ctx->vox = nullptr;
+            }
+            return rc;
+        }
+    }
     return VRM_OK;
 }
 
