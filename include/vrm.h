@@ -201,7 +201,7 @@ VRM_API int vrm_write_netcdf(vrm_ctx *ctx, const char *path);
 /* The same volume in the container the reference's own writer makes (`netcdf::create`, netcdf.rs:10): NetCDF-4 = HDF5,
  * in the oldest dialect of that format (superblock 0, symbol-table root group, contiguous little-endian `color`, the
  * dimensions as dimension-scale datasets with netcdf-c's CLASS / NAME / _Netcdf4Dimid attributes, `color` with
- * _Netcdf4Coordinates).  Parity unpinned: checked against this library's reader and a second restatement of the
+ * _Netcdf4Coordinates).  Checked against the HDF5 library (libhdf5 1.10.6's h5dump reads it: tests/test_hdf5_golden_cpu.py), this library's reader and a second restatement of the
  * specification (tests/hdf5_builder.py), not against netcdf-c, which does not exist in the build environment. */
 VRM_API int vrm_write_netcdf4(vrm_ctx *ctx, const char *path);
 /* The container alone, host only (no context, no GPU): with color_czyx == NULL a size query that sets x, y, z;

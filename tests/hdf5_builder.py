@@ -1,7 +1,8 @@
 """Hand-assembled NetCDF-4 / HDF5 files for tests/test_hdf5_cpu.py.
 
-No HDF5 or netCDF library exists in this environment (h5py, netCDF4, pytables are not importable; the reference tree holds no
-data files), so there is nothing to read back that such a library wrote: these files are assembled byte by byte from the
+No HDF5 or netCDF module is importable by the tests' interpreter (h5py, netCDF4, pytables; the reference tree holds no data
+files) -- files the HDF5 C library wrote are under tests/golden/hdf5/ (test_hdf5_golden_cpu.py) --, and the dialects, damage and
+corner cases those do not hold are assembled here byte by byte from the
 published HDF5 File Format Specification (version 3.0, sections III.A superblock, III.C object headers, III.A.1/IV.A.2 B-trees,
 symbol table nodes, local heaps, IV.A.2.b dataspace, .d datatype, .i data layout, .l filter pipeline, .g link, .c link info),
 in the two dialects a netCDF-4 file of five objects can come in:
@@ -12,8 +13,11 @@ in the two dialects a netCDF-4 file of five objects can come in:
   with creation order, `color` chunked through a two-level version-1 chunk B-tree with shuffle + deflate, big-endian floats,
   one chunk never written, one chunk stored with the deflate filter masked out.
 
-PARITY UNPINNED: reader (csrc/vrm_hdf5.cpp) and these builders restate the same specification; a misreading shared by both
-would not show here.  Checksums of version-2 structures are Jenkins' lookup3 as published; the reader does not verify them.
+Reader (csrc/vrm_hdf5.cpp) and these builders restate the same specification, so a misreading shared by both would not show in
+test_hdf5_cpu.py alone: tests/test_hdf5_golden_cpu.py therefore hands every dialect built here to the HDF5 library's own h5dump
+(where this image has it) and requires the values the tests expect -- which found two things the specification's text does not
+say: B-tree and symbol-table nodes are read at their FULL size whatever they hold, and an empty local-heap free list is 1.
+Checksums of version-2 structures are Jenkins' lookup3 as published (the library verifies them; the reader does not).
 """
 import struct
 import zlib
@@ -227,7 +231,7 @@ def netcdf4_classic_model(color):
         heap_data += n.encode() + b"\0"
         heap_data += b"\0" * (-len(heap_data) % 8)
     heap_data_addr = img.append(bytes(heap_data))
-    heap = img.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, heap_data_addr))
+    heap = img.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, heap_data_addr))  # free list empty: libhdf5 writes 1 (H5HL_FREE_NULL), found with the real library (tests/test_hdf5_golden_cpu.py)
     leaf_k, internal_k = 4, 16
     snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
     for n in names:
@@ -271,12 +275,14 @@ def old_style(color, dims_extra=None):
         heap_data += n.encode() + b"\0"
         heap_data += b"\0" * (-len(heap_data) % 8)
     heap_data_addr = img.append(bytes(heap_data))
-    heap = img.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, heap_data_addr))
+    heap = img.append(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, heap_data_addr))  # free list empty: libhdf5 writes 1 (H5HL_FREE_NULL), found with the real library (tests/test_hdf5_golden_cpu.py)
     snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
     for n in names:
         snod += struct.pack("<QQII16x", name_off[n], objs[n], 0, 0)
-    snod_addr = img.append(snod)
+    snod += b"\0" * ((2 * 4 - len(names)) * 40)      # (nodes are stored at their full size -- 2K entries, 2K children and 2K+1
+    snod_addr = img.append(snod)                     # keys -- whatever they hold: libhdf5 reads the whole node)
     tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, name_off[names[-1]])
+    tree += b"\0" * ((2 * 16 - 1) * 16)
     tree_addr = img.append(tree)
     root = object_header_v1(img, [(0x11, msg_symbol_table(tree_addr, heap)), (0x0C, msg_attribute_v1("_NCProperties", "version=2"))])
     eof = len(img.b)
@@ -339,6 +345,7 @@ def new_style(color, chunk=(2, 3, 4, 5), skip_chunk=1, unfiltered_chunk=2, filte
         for size, mask, origin, child in entries:
             body += key(size, mask, origin) + struct.pack("<Q", child)
         body += key(0, 0, last_origin)
+        body += b"\0" * (24 + 64 * 8 + 65 * 48 - 24 - len(body))   # stored at full size (K = 32: 64 children, 65 keys): libhdf5 reads all of it
         return img.append(b"TREE" + struct.pack("<BBHQQ", 1, level, len(entries), UNDEF, UNDEF) + body)
     end_origin = tuple(color.shape)
     half = max(1, len(leaves) // 2)

@@ -378,7 +378,7 @@ def test_export_error_path_joins_and_reports(vr, tmp_path):
 
 def test_netcdf4_hdf5_load(rm1, vr, orc, tmp_path):
     """open_voxel_grid on a NetCDF-4 = HDF5 container (what the reference's netcdf crate and diffdvr.py write): both dialects of
-    tests/hdf5_builder.py through vrm_load_netcdf, quantised on the GPU like the classic path.  Parity unpinned (see the builder)."""
+    tests/hdf5_builder.py through vrm_load_netcdf, quantised on the GPU like the classic path.  (The container is pinned against libhdf5 in test_hdf5_golden_cpu.py.)"""
     import hdf5_builder as hb
     rng = np.random.default_rng(11)
     data = (rng.random((4, 6, 10, 9), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)    # values below 0 and above 1 as well
@@ -393,6 +393,17 @@ def test_netcdf4_hdf5_load(rm1, vr, orc, tmp_path):
         g = rm1.voxel_grid
         assert g.dimensions == (9, 10, 6) and list(g.uniform().buffer) == [1.0] * 4
         assert np.array_equal(g.download_rgba8(), orc.quantize_netcdf(data))
+    # ... and files the HDF5 library itself wrote (tests/golden/hdf5, tools/make_hdf5_golden.c): the dialect netcdf-c's defaults give,
+    # a chunked + shuffled + deflated one, and one whose never-written chunks read as netCDF's fill value (9.97e36 -> 255 as u8)
+    from test_hdf5_golden_cpu import GOLDEN, LIB_FILES, NC_FILL_FLOAT, golden_values
+    for name in ("lib_earliest_contiguous", "lib_v18_deflate_shuffle", "lib_fill_value"):
+        z, y, x = LIB_FILES[name]
+        want = golden_values(z, y, x)
+        if name == "lib_fill_value":
+            want[:, 2:] = NC_FILL_FLOAT
+        rm1.load_netcdf(os.path.join(GOLDEN, name + ".nc"))
+        assert rm1.voxel_grid.dimensions == (x, y, z)
+        assert np.array_equal(rm1.voxel_grid.download_rgba8(), orc.quantize_netcdf(want)), name
 
 
 def test_library_broadcast_single_rank(vr, orc):

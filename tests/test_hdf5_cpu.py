@@ -1,7 +1,7 @@
 """NetCDF-4 = HDF5 container of `color(c,z,y,x)` (f-2; host code of libvrm.so, no GPU): the reader of csrc/vrm_hdf5.cpp against
 files assembled byte by byte from the HDF5 File Format Specification (tests/hdf5_builder.py) in the dialects a netCDF-4 file of
-this shape can come in.  PARITY UNPINNED: no netcdf-c / h5py / netCDF4 exists here to write a file to read back, and the
-reference tree holds no data files; what is pinned is the reader against the published format as restated by the builder."""
+this shape can come in, with the damage and corner cases no library writes.  The pin against the HDF5 library itself -- files it
+wrote, and its own reading of the builder's files and of the writer's -- is tests/test_hdf5_golden_cpu.py."""
 import os
 
 import numpy as np
@@ -149,7 +149,7 @@ def test_chunk_larger_than_the_dataset_is_refused(tmp_path):
 def test_writer_round_trip_and_second_restatement(tmp_path, shape):
     """vrm_netcdf_write_color_nc4 (what `netcdf::create` + put_values of netcdf.rs:10-29 leave on disk, oldest HDF5 dialect):
     the reader returns the array bit for bit, and the file equals, byte for byte, the one tests/hdf5_builder.py assembles for the
-    same array from the specification.  PARITY UNPINNED against netcdf-c itself (not available here)."""
+    same array from the specification.  Read by the HDF5 library itself in test_hdf5_golden_cpu.py; netcdf-c is not available here."""
     d = _data(shape, 7)
     p = os.path.join(tmp_path, "w.nc")
     netcdf.write_color(p, d, format="netcdf4")

@@ -3,19 +3,23 @@
 // `netcdf::create` / `netcdf::open` in loaders/netcdf.rs:10,35 and `Dataset(..., format='NETCDF4_CLASSIC')` in
 // scripts/diffdvr.py:278 produce NetCDF-4 files, i.e. HDF5 containers: the variable `color(c,z,y,x)` is an HDF5 dataset
 // named "color" in the root group, the dimensions c, z, y, x are (dimension-scale) datasets beside it.  netcdf-c and the
-// HDF5 library are dependencies of the reference that are neither in its tree nor in this image, so this is a reader for
-// the subset of the published HDF5 File Format Specification (version 3.0) that such files use, restated from the
-// specification:
+// HDF5 library are dependencies of the reference that are not in its tree and that this library does not link, so this is
+// a reader for the subset of the published HDF5 File Format Specification (version 3.0) that such files use, restated
+// from the specification:
 //   * superblock versions 0, 1 (symbol-table root) and 2, 3 (root object header address);
 //   * object headers version 1 and version 2 ("OHDR"), with continuation blocks ("OCHK" for version 2);
-//   * groups as a symbol table (B-tree version 1 "TREE" of "SNOD" nodes + local "HEAP") and as compact link messages
-//     (what netcdf-c's creation-order tracking produces for a handful of objects); dense link storage (fractal heap)
-//     is recognised and refused;
-//   * the dataset's dataspace (versions 1, 2), datatype (IEEE f32, little or big endian) and data layout message
-//     version 3 -- contiguous, or chunked through a version-1 chunk B-tree -- and version 4 contiguous / single-chunk;
+//   * groups as a symbol table (B-tree version 1 "TREE" of "SNOD" nodes + local "HEAP"), as compact link messages
+//     (what netcdf-c's creation-order tracking produces for a handful of objects) and as dense link storage (more than
+//     8 objects: fractal heap "FRHP" + version-2 B-tree name index, up to about a thousand links);
+//   * the dataset's dataspace (versions 1, 2), datatype (IEEE f32, little or big endian), fill value, and data layout
+//     message version 3 -- compact, contiguous, or chunked through a version-1 chunk B-tree -- and version 4: compact,
+//     contiguous, single-chunk, implicit and fixed-array chunk indexes (the indexes of datasets with unlimited dimensions,
+//     extensible array and version-2 B-tree, are recognised and refused);
 //   * the filter pipeline with deflate (zlib), shuffle and fletcher32 (checksum not verified), the filters netCDF-4 offers.
-// PARITY UNPINNED: no file written by netcdf-c / h5py / netCDF4 exists in this environment to read back; the tests
-// assemble files byte by byte from the same specification (tests/hdf5_builder.py).
+// PINNED against the HDF5 library itself (round 3): tests/golden/hdf5/lib_*.nc were written by libhdf5 1.10.6 through the
+// calls netcdf-c makes (tools/make_hdf5_golden.c) in every one of these dialects and are read back bit for bit
+// (tests/test_hdf5_golden_cpu.py); the byte-built files of tests/hdf5_builder.py are read by the library's own h5dump with
+// the values the tests expect.  What stays unpinned is netcdf-c's layer above HDF5 (absent here).
 #include <zlib.h>
 
 #include <algorithm>
@@ -166,8 +170,124 @@ std::vector<Message> object_header(H5 &h, uint64_t addr)
     return out;
 }
 
+typedef std::vector<std::pair<std::string, uint64_t>> Links;
+
+// one link message (in an object header, or as an object of a dense group's fractal heap)
+void parse_link(H5 &h, const uint8_t *data, size_t n, Links &links)
+{
+    Cur c(h, data, n);
+    if (c.u(1) != 1) h.fail("link message version is not 1");
+    const uint8_t fl = (uint8_t)c.u(1);
+    uint8_t ltype = 0;
+    if (fl & 0x08) ltype = (uint8_t)c.u(1);
+    if (fl & 0x04) c.skip(8);
+    if (fl & 0x10) c.skip(1);
+    const uint64_t nlen = c.u(1 << (fl & 3));
+    c.need((size_t)nlen);
+    std::string name(reinterpret_cast<const char *>(c.p), (size_t)nlen);
+    c.skip((size_t)nlen);
+    if (ltype == 0) links.emplace_back(name, c.off()); // hard link; soft / external links are not followed
+}
+
+int bits_of(uint64_t v) { int b = 0; while (v >>= 1) ++b; return b; } // floor(log2 v)
+
+// Dense link storage (a group of more than 8 objects, or one that has held that many): the links are objects of a fractal heap
+// "FRHP", found through the records of the name index, a version-2 B-tree "BTHD" of type 5 (hash of the name + heap ID).
+// Read: heaps without I/O filters whose root is a direct block or an indirect block of direct blocks (group heaps start with
+// 512-byte blocks, four to a row, up to 64 KB: half a megabyte of links), managed objects only; B-trees of depth 0 and 1.
+void dense_links(H5 &h, uint64_t heap_addr, uint64_t index_addr, Links &links)
+{
+    auto hb = h.block(heap_addr, (size_t)(4 + 1 + 2 + 2 + 1 + 4 + h.sl + h.so + h.sl + h.so + 8 * h.sl + 2 + 2 * h.sl + 2 + 2 + h.so + 2));
+    if (memcmp(hb.data(), "FRHP", 4) != 0) h.fail("bad fractal heap signature");
+    Cur c(h, hb.data() + 4, hb.size() - 4);
+    if (c.u(1) != 0) h.fail("fractal heap version");
+    const uint64_t id_len = c.u(2), filter_len = c.u(2);
+    c.u(1);                  // flags (bit 1: direct blocks are checksummed -- the checksum trails the block, nothing moves)
+    const uint64_t max_managed = c.u(4);
+    c.len(); c.off();        // huge objects
+    c.len(); c.off();        // free space
+    c.len(); c.len(); c.len(); c.len(); // managed space, allocated, iterator offset, number of managed objects
+    c.len(); c.len(); c.len(); c.len(); // huge / tiny sizes and counts
+    const uint64_t width = c.u(2), start = c.len(), max_direct = c.len(), heap_bits = c.u(2);
+    c.u(2);
+    const uint64_t root = c.off(), root_rows = c.u(2);
+    if (filter_len != 0) h.fail("fractal heap with I/O filters is not read");
+    if (width == 0 || width > 1024 || start < 16 || (start & (start - 1)) || max_direct < start || (max_direct & (max_direct - 1)) || max_direct > ((uint64_t)1 << 26) || heap_bits == 0 || heap_bits > 64)
+        h.fail("fractal heap parameters are not plausible");
+    const size_t off_size = (size_t)((heap_bits + 7) / 8);
+    const size_t len_size = (size_t)std::min<int>((bits_of(max_direct) + 7) / 8, bits_of(max_managed ? max_managed : 1) / 8 + 1);
+    if (1 + off_size + len_size > id_len) h.fail("fractal heap IDs of %llu bytes", (unsigned long long)id_len);
+    // the direct blocks: (offset in the heap's address space, size, file address)
+    struct Block { uint64_t off, size, addr; };
+    std::vector<Block> blocks;
+    if (root == UNDEF) return; // an empty heap
+    if (root_rows == 0) {
+        blocks.push_back({0, start, root});
+    } else {
+        const uint64_t max_direct_rows = (uint64_t)(bits_of(max_direct) - bits_of(start)) + 2;
+        if (root_rows > max_direct_rows) h.fail("the root group holds more links than this reader follows (fractal heap with nested indirect blocks)");
+        auto ib = h.block(root, (size_t)(4 + 1 + h.so + off_size + root_rows * width * h.so));
+        if (memcmp(ib.data(), "FHIB", 4) != 0) h.fail("bad fractal heap indirect block signature");
+        Cur ic(h, ib.data() + 5 + h.so + off_size, ib.size() - 5 - (size_t)h.so - off_size);
+        uint64_t off = 0;
+        for (uint64_t r = 0; r < root_rows; ++r) {
+            const uint64_t size = r < 2 ? start : start << (r - 1);
+            for (uint64_t k = 0; k < width; ++k, off += size) {
+                const uint64_t a = ic.off();
+                if (a != UNDEF) blocks.push_back({off, size, a});
+            }
+        }
+    }
+    auto heap_object = [&](const uint8_t *id) {
+        if ((id[0] & 0x30) != 0) h.fail("a link is stored as a huge or tiny heap object: not read");
+        uint64_t off = 0, len = 0;
+        for (size_t i = 0; i < off_size; ++i) off |= (uint64_t)id[1 + i] << (8 * i);
+        for (size_t i = 0; i < len_size; ++i) len |= (uint64_t)id[1 + off_size + i] << (8 * i);
+        for (const Block &b : blocks)
+            if (off >= b.off && off - b.off < b.size) {
+                if (len == 0 || len > b.size - (off - b.off)) break;
+                auto data = h.block(b.addr + (off - b.off), (size_t)len);
+                parse_link(h, data.data(), data.size(), links);
+                return;
+            }
+        h.fail("a link's heap ID points outside the heap's blocks");
+    };
+    // the name index
+    auto tb = h.block(index_addr, (size_t)(4 + 1 + 1 + 4 + 2 + 2 + 1 + 1 + h.so + 2 + h.sl));
+    if (memcmp(tb.data(), "BTHD", 4) != 0) h.fail("bad version-2 B-tree header signature");
+    Cur tc(h, tb.data() + 4, tb.size() - 4);
+    if (tc.u(1) != 0) h.fail("version-2 B-tree header version");
+    const uint64_t type = tc.u(1), node_size = tc.u(4), rec_size = tc.u(2), depth = tc.u(2);
+    tc.u(2);
+    const uint64_t root_node = tc.off(), root_nrec = tc.u(2);
+    if (type != 5 || rec_size != 4 + id_len || node_size < 32 || node_size > ((uint64_t)1 << 24)) h.fail("the root group's name index is not a type-5 B-tree of hash + heap ID records");
+    if (depth > 1) h.fail("the root group holds more links than this reader follows (name index of depth %llu)", (unsigned long long)depth);
+    if (root_node == UNDEF) return;
+    auto leaf = [&](uint64_t addr, uint64_t nrec) {
+        if (nrec * rec_size + 10 > node_size) h.fail("version-2 B-tree leaf of %llu records", (unsigned long long)nrec);
+        auto nb = h.block(addr, (size_t)(6 + nrec * rec_size));
+        if (memcmp(nb.data(), "BTLF", 4) != 0) h.fail("bad version-2 B-tree leaf signature");
+        for (uint64_t i = 0; i < nrec; ++i) heap_object(nb.data() + 6 + i * rec_size + 4);
+    };
+    if (depth == 0) {
+        leaf(root_node, root_nrec);
+    } else {
+        const uint64_t max_leaf = (node_size - 10) / rec_size;
+        const size_t nrec_size = (size_t)(bits_of(max_leaf ? max_leaf : 1) / 8 + 1);
+        if (root_nrec * rec_size + (root_nrec + 1) * (h.so + nrec_size) + 10 > node_size) h.fail("version-2 B-tree internal node of %llu records", (unsigned long long)root_nrec);
+        auto nb = h.block(root_node, (size_t)(6 + root_nrec * rec_size + (root_nrec + 1) * (h.so + nrec_size)));
+        if (memcmp(nb.data(), "BTIN", 4) != 0) h.fail("bad version-2 B-tree internal node signature");
+        for (uint64_t i = 0; i < root_nrec; ++i) heap_object(nb.data() + 6 + i * rec_size + 4);
+        Cur pc(h, nb.data() + 6 + root_nrec * rec_size, (size_t)((root_nrec + 1) * (h.so + nrec_size)));
+        for (uint64_t i = 0; i <= root_nrec; ++i) {
+            const uint64_t child = pc.off(), n = pc.u((int)nrec_size);
+            leaf(child, n);
+        }
+    }
+}
+
 // name -> object header address of every link of a group
-void group_links(H5 &h, const std::vector<Message> &msgs, std::vector<std::pair<std::string, uint64_t>> &links)
+void group_links(H5 &h, const std::vector<Message> &msgs, Links &links)
 {
     for (const Message &m : msgs) {
         if (m.type == 0x0011) { // symbol table: B-tree v1 + local heap
@@ -219,26 +339,14 @@ void group_links(H5 &h, const std::vector<Message> &msgs, std::vector<std::pair<
                 }
             }
         } else if (m.type == 0x0006) { // link message
-            Cur c(h, m.data.data(), m.data.size());
-            if (c.u(1) != 1) h.fail("link message version is not 1");
-            const uint8_t fl = (uint8_t)c.u(1);
-            uint8_t ltype = 0;
-            if (fl & 0x08) ltype = (uint8_t)c.u(1);
-            if (fl & 0x04) c.skip(8);
-            if (fl & 0x10) c.skip(1);
-            const uint64_t nlen = c.u(1 << (fl & 3));
-            c.need((size_t)nlen);
-            std::string name(reinterpret_cast<const char *>(c.p), (size_t)nlen);
-            c.skip((size_t)nlen);
-            if (ltype == 0) links.emplace_back(name, c.off()); // hard link; soft / external links are not followed
+            parse_link(h, m.data.data(), m.data.size(), links);
         } else if (m.type == 0x0002) { // link info: dense storage?
             Cur c(h, m.data.data(), m.data.size());
             c.u(1);
             const uint8_t fl = (uint8_t)c.u(1);
             if (fl & 1) c.skip(8);
-            if (c.off() != UNDEF)
-                h.fail("the root group stores its links densely (fractal heap: more than 8 objects); only compact link messages and "
-                       "symbol-table groups are read");
+            const uint64_t heap = c.off(), index = c.off();
+            if (heap != UNDEF) dense_links(h, heap, index, links);
         }
     }
 }
@@ -246,8 +354,11 @@ void group_links(H5 &h, const std::vector<Message> &msgs, std::vector<std::pair<
 struct Dataset {
     std::vector<uint64_t> dims;
     bool big_endian = false;
-    int layout = -1; // 1 contiguous, 2 chunked (B-tree v1), 3 single chunk
+    int layout = -1; // 0 compact, 1 contiguous, 2 chunked (B-tree v1), 3 single chunk, 4 implicit chunk index, 5 fixed-array chunk index
     uint64_t addr = UNDEF, size = 0;
+    std::vector<uint8_t> compact; // layout 0: the data itself, from the layout message
+    bool filtered_index = false;  // layout 5: the index entries carry a stored size and a filter mask
+    uint8_t fill[4] = {0, 0, 0, 0}; // the dataset's fill value in the FILE's byte order (what never-written storage reads as)
     std::vector<uint64_t> chunk; // chunk dims (elements), rank entries
     struct Filter { uint16_t id; };
     std::vector<Filter> filters;
@@ -293,8 +404,13 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                     d.addr = c.off();
                     for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u(4));
                     if (c.u(4) != 4) h.fail("chunk element size is not 4");
+                } else if (cls == 0) {
+                    d.layout = 0;
+                    d.size = c.u(2);
+                    c.need((size_t)d.size);
+                    d.compact.assign(c.p, c.p + d.size);
                 } else {
-                    h.fail("compact dataset storage is not read");
+                    h.fail("data layout class %llu is not read", (unsigned long long)cls);
                 }
             } else if (ver == 4) {
                 const uint64_t cls = c.u(1);
@@ -302,21 +418,48 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                     d.layout = 1;
                     d.addr = c.off();
                     d.size = c.len();
+                } else if (cls == 0) {
+                    d.layout = 0;
+                    d.size = c.u(2);
+                    c.need((size_t)d.size);
+                    d.compact.assign(c.p, c.p + d.size);
                 } else if (cls == 2) {
                     const uint64_t fl = c.u(1), nd = c.u(1), enc = c.u(1);
                     if (enc < 1 || enc > 8) h.fail("chunk dimension size encoded in %llu bytes", (unsigned long long)enc);
                     for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u((int)enc));
                     c.u((int)enc);
                     const uint64_t idx = c.u(1);
-                    if (idx != 1) h.fail("version-4 chunk index type %llu is not read (only contiguous, version-1 B-tree and single-chunk layouts)", (unsigned long long)idx);
-                    d.layout = 3;
-                    if (fl & 2) { d.size = c.len(); d.single_filter_mask = (uint32_t)c.u(4); }
+                    if (idx == 1) { // single chunk
+                        d.layout = 3;
+                        if (fl & 2) { d.size = c.len(); d.single_filter_mask = (uint32_t)c.u(4); }
+                    } else if (idx == 2) { // implicit: every chunk allocated, unfiltered, one after the other in row-major chunk order
+                        d.layout = 4;
+                    } else if (idx == 3) { // fixed array (no unlimited dimension): what HDF5 1.10's "latest" format writes
+                        d.layout = 5;
+                        c.u(1); // page bits: repeated in the array's header
+                    } else {
+                        h.fail("version-4 chunk index type %llu is not read (extensible array / version-2 B-tree: datasets with unlimited dimensions)", (unsigned long long)idx);
+                    }
                     d.addr = c.off();
                 } else {
                     h.fail("data layout class %llu is not read", (unsigned long long)cls);
                 }
             } else {
                 h.fail("data layout message version %llu is not read (HDF5 older than 1.6.3)", (unsigned long long)ver);
+            }
+        } else if (m.type == 0x0005) { // fill value: what storage that was never written reads as (netcdf-c defines one for every variable)
+            const uint64_t ver = c.u(1);
+            bool defined = false;
+            if (ver == 1 || ver == 2) {
+                c.skip(2);
+                defined = c.u(1) != 0;
+                if (ver == 1) defined = true; // (version 1 always carries the size field)
+            } else if (ver == 3) {
+                defined = (c.u(1) & 0x20) != 0;
+            }
+            if (defined && c.left() >= 4) {
+                const uint64_t sz = c.u(4);
+                if (sz == 4 && c.left() >= 4) memcpy(d.fill, c.p, 4);
             }
         } else if (m.type == 0x000B) { // filter pipeline
             const uint64_t ver = c.u(1), n = c.u(1);
@@ -413,6 +556,72 @@ void read_chunked(H5 &h, const Dataset &d, float *out)
         return;
     }
     if (d.addr == UNDEF) return;
+    if (d.layout == 4 || d.layout == 5) {
+        // version-4 layouts index the chunks by their number in row-major order over the chunk grid
+        uint64_t grid[4], total = 1;
+        for (size_t k = 0; k < 4; ++k) {
+            grid[k] = (d.dims[k] + d.chunk[k] - 1) / d.chunk[k];
+            if (__builtin_mul_overflow(total, grid[k], &total)) h.fail("chunk grid is not plausible");
+        }
+        if (total > h.file_size) h.fail("%llu chunks in a file of %llu bytes", (unsigned long long)total, (unsigned long long)h.file_size);
+        auto origin_of = [&](uint64_t i) {
+            std::vector<uint64_t> o(4);
+            for (int k = 3; k >= 0; --k) { o[(size_t)k] = (i % grid[k]) * d.chunk[(size_t)k]; i /= grid[k]; }
+            return o;
+        };
+        if (d.layout == 4) {
+            if (!d.filters.empty()) h.fail("implicit chunk index on a filtered dataset");
+            for (uint64_t i = 0; i < total; ++i) {
+                decode_chunk(h, d, d.addr + i * chunk_bytes, chunk_bytes, 0, chunk_bytes, raw, tmp);
+                copy_chunk(d, origin_of(i), raw.data(), out);
+            }
+            return;
+        }
+        // fixed array: header "FAHD" -> data block "FADB", its elements in pages once there are more than 2^page_bits of them
+        auto hb = h.block(d.addr, (size_t)(8 + h.sl + h.so + 4));
+        if (memcmp(hb.data(), "FAHD", 4) != 0) h.fail("bad fixed-array header signature");
+        Cur hc(h, hb.data() + 4, hb.size() - 4);
+        if (hc.u(1) != 0) h.fail("fixed-array header version");
+        const uint64_t client = hc.u(1), esz = hc.u(1), page_bits = hc.u(1), nelem = hc.len(), dblk = hc.off();
+        const bool filtered = client == 1;
+        if (client > 1 || nelem < total || page_bits > 30) h.fail("fixed array of %llu entries for %llu chunks", (unsigned long long)nelem, (unsigned long long)total);
+        if (esz < (uint64_t)h.so + (filtered ? 5 : 0) || esz > (uint64_t)h.so + 12) h.fail("fixed-array entries of %llu bytes", (unsigned long long)esz);
+        if (filtered == d.filters.empty()) h.fail("fixed-array client does not match the filter pipeline");
+        if (dblk == UNDEF) return; // nothing written yet
+        const uint64_t per_page = (uint64_t)1 << page_bits;
+        const bool paged = nelem > per_page;
+        const uint64_t npages = paged ? (nelem + per_page - 1) / per_page : 0, bitmap_bytes = (npages + 7) / 8;
+        const uint64_t prefix = 4 + 1 + 1 + (uint64_t)h.so; // signature, version, client, header address
+        auto db = h.block(dblk, (size_t)(prefix + bitmap_bytes));
+        if (memcmp(db.data(), "FADB", 4) != 0) h.fail("bad fixed-array data block signature");
+        auto element = [&](const uint8_t *e, uint64_t i) {
+            Cur ec(h, e, (size_t)esz);
+            const uint64_t addr = ec.off();
+            uint64_t stored = chunk_bytes;
+            uint32_t mask = 0;
+            if (filtered) { stored = ec.u((int)(esz - (uint64_t)h.so - 4)); mask = (uint32_t)ec.u(4); }
+            if (addr == UNDEF) return; // never written: the fill value
+            decode_chunk(h, d, addr, stored, mask, chunk_bytes, raw, tmp);
+            copy_chunk(d, origin_of(i), raw.data(), out);
+        };
+        if (!paged) {
+            auto eb = h.block(dblk + prefix, (size_t)(total * esz));
+            for (uint64_t i = 0; i < total; ++i) element(eb.data() + i * esz, i);
+        } else {
+            // (pages follow the data block's prefix, bitmap and checksum; each is 2^page_bits entries -- the last one what is left --
+            // and a checksum; a page whose bit is clear was never written)
+            uint64_t at = dblk + prefix + bitmap_bytes + 4;
+            for (uint64_t pg = 0; pg < npages; ++pg) {
+                const uint64_t first = pg * per_page, cnt = std::min<uint64_t>(per_page, nelem - first);
+                if (db[(size_t)(prefix + pg / 8)] & (0x80u >> (pg % 8))) {   // (most significant bit first)
+                    auto eb = h.block(at, (size_t)(cnt * esz));
+                    for (uint64_t i = 0; i < cnt && first + i < total; ++i) element(eb.data() + i * esz, first + i);
+                    at += cnt * esz + 4;
+                }
+            }
+        }
+        return;
+    }
     std::vector<uint64_t> nodes{d.addr};
     size_t visited = 0;
     const size_t key = 8 + 8 * 5; // chunk size, filter mask, 5 offsets of 8 bytes (rank + 1)
@@ -498,7 +707,7 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
             h.fail("superblock version %llu is not read", (unsigned long long)ver);
         }
         root_msgs = object_header(h, root);
-        std::vector<std::pair<std::string, uint64_t>> links;
+        Links links;
         group_links(h, root_msgs, links);
         uint64_t color = UNDEF;
         uint64_t named[3] = {UNDEF, UNDEF, UNDEF};
@@ -545,16 +754,25 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
             vrm_set_error("%s holds %llu floats, buffer holds %zu", path, (unsigned long long)n, capacity_floats);
             return VRM_ERR_INVALID;
         }
-        if (d.layout == 1) {
+        auto fill_all = [&] { // storage that was never written reads as the dataset's fill value (zero bytes unless the file defines one)
+            uint32_t w;
+            memcpy(&w, d.fill, 4);
+            if (w == 0) memset(out, 0, (size_t)n * 4);
+            else for (uint64_t i = 0; i < n; ++i) memcpy(out + i, &w, 4);
+        };
+        if (d.layout == 0) {
+            if (d.compact.size() < n * 4) h.fail("compact storage of %zu bytes is shorter than the %llu the dimensions need", d.compact.size(), (unsigned long long)(n * 4));
+            memcpy(out, d.compact.data(), (size_t)n * 4);
+        } else if (d.layout == 1) {
             if (d.addr == UNDEF) {
-                memset(out, 0, (size_t)n * 4); // never written: the fill value
+                fill_all();
             } else {
                 if (d.size < n * 4) h.fail("contiguous storage of %llu bytes is shorter than the %llu the dimensions need", (unsigned long long)d.size, (unsigned long long)(n * 4));
                 const size_t step = (size_t)1 << 26;
                 for (uint64_t done = 0; done < n * 4; done += step) h.read(d.addr + done, reinterpret_cast<uint8_t *>(out) + done, (size_t)std::min<uint64_t>(step, n * 4 - done));
             }
         } else {
-            memset(out, 0, (size_t)n * 4); // chunks that were never written read as the fill value
+            fill_all(); // chunks that were never written
             read_chunked(h, d, out);
         }
         if (d.big_endian) {
@@ -576,9 +794,12 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
 // dataset, and the four dimensions c, z, y, x as dimension-scale datasets without storage that carry netcdf-c's
 // attributes (CLASS, NAME, _Netcdf4Dimid); `color` carries _Netcdf4Coordinates = {0,1,2,3}, the attribute netcdf-c
 // reads the dimension ids of a variable from, so no object references (DIMENSION_LIST / REFERENCE_LIST) are written.
-// PARITY UNPINNED, like the reader above: no HDF5 / netCDF library exists here to open the result with.  The tests pin it
-// two ways: the reader above reads it back bit for bit, and tests/hdf5_builder.py, a second restatement of the same
-// specification in another language, assembles the same file byte for byte.
+// PINNED against the HDF5 library (tests/test_hdf5_golden_cpu.py): libhdf5 1.10.6's own h5dump opens the result, lists the five
+// datasets with their shapes, types and attributes and returns the values that went in -- which is how the one place where
+// the library departs from the published format was found (the local heap's empty free list is stored as 1, not as the
+// undefined address).  Also read back bit for bit by the reader above, and assembled byte for byte by tests/hdf5_builder.py,
+// a second restatement in another language.  netcdf-c itself is not available here: that it takes the dimension ids from
+// `_Netcdf4Coordinates` is from its source, not from a run.
 namespace {
 
 struct Bytes {
@@ -709,7 +930,7 @@ int vrm_hdf5_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, c
     img.cat(heap);
     img.pad8();
     const uint64_t heap_addr = base + img.b.size();
-    img.raw("HEAP", 4); img.u(0, 1); img.zeros(3); img.u(heap.b.size(), 8); img.u(UNDEF, 8); img.u(heap_data, 8);
+    img.raw("HEAP", 4); img.u(0, 1); img.zeros(3); img.u(heap.b.size(), 8); img.u(1, 8); img.u(heap_data, 8); // (free list empty: the library writes 1 here, H5HL_FREE_NULL, not the undefined address)
     img.pad8();
     const uint64_t snod = base + img.b.size();
     img.raw("SNOD", 4); img.u(1, 1); img.u(0, 1); img.u(5, 2);

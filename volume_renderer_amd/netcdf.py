@@ -1,7 +1,8 @@
 """NetCDF interchange of the path: `color(c,z,y,x)` f32 through libvrm.so (vrm_netcdf_read_color /
 vrm_netcdf_write_color; host code, no GPU needed).  Read: the netCDF classic containers (CDF-1/2/5) and NetCDF-4 = HDF5, what
 the reference's own netcdf crate and scripts/diffdvr.py:278 write (csrc/vrm_hdf5.cpp).  Written: classic, which netcdf-c reads,
-or (`format="netcdf4"`) the HDF5 container `netcdf::create` itself makes, in its oldest dialect (parity unpinned)."""
+or (`format="netcdf4"`) the HDF5 container `netcdf::create` itself makes, in its oldest dialect.  Reader and writer are pinned against libhdf5
+itself (tests/test_hdf5_golden_cpu.py)."""
 import ctypes
 import os
 
