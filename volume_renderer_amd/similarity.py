@@ -10,9 +10,9 @@ The PNGs are decoded by vrm_png_read and the sum of squared differences is an ex
 GPU (vrm_ssd_u8), so mse is bit-identical to skimage's.  ssim = structural_similarity(img_gt, img_approx,
 data_range = img_gt.max() - img_approx.min(), channel_axis=-1) (similarity.py:64-65; the data range is the
 script's own, formed in uint8 arithmetic as numpy forms it) through vrm_ssim_u8, which restates scikit-image's
-published defaults (7x7 uniform window, K1 0.01, K2 0.03, sample covariance, f64, cropped border).  scikit-image
-is not available where this was written: the SSIM column is checked against an independent scipy restatement
-only -- parity unpinned.  A 2-D (gray) image counts as one channel.
+published defaults (7x7 uniform window, K1 0.01, K2 0.03, sample covariance, f64, cropped border).  Pinned against
+scikit-image 0.18.3 itself (tests/golden/similarity: what the library returns for these calls on 16 image pairs; mse and
+psnr equal, ssim within 1e-12) and against an independent scipy restatement.  A 2-D (gray) image counts as one channel.
 """
 import argparse
 import ctypes
