@@ -205,7 +205,9 @@ VRM_API int vrm_write_netcdf(vrm_ctx *ctx, const char *path);
  * specification (tests/hdf5_builder.py), not against netcdf-c, which does not exist in the build environment. */
 VRM_API int vrm_write_netcdf4(vrm_ctx *ctx, const char *path);
 /* The container alone, host only (no context, no GPU): with color_czyx == NULL a size query that sets x, y, z;
- * otherwise 4*x*y*z floats in file order (c slowest, x fastest) converted to host byte order. */
+ * otherwise 4*x*y*z floats in file order (c slowest, x fastest) converted to host byte order.  `color` stored as another
+ * numeric type (double, integers) is handed over as (float)value, the conversion of netcdf-c's nc_get_vara_float behind the
+ * reference's get::<f32> (netcdf.rs:45; a double beyond the range of f32 is NC_ERANGE there and VRM_ERR_IO here, text is refused). */
 VRM_API int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y, uint32_t *z, float *color_czyx,
                                   size_t capacity_floats);
 VRM_API int vrm_netcdf_write_color(const char *path, uint32_t x, uint32_t y, uint32_t z, const float *color_czyx);

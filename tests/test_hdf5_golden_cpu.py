@@ -28,6 +28,7 @@ LIB_FILES = {
     "lib_v18_fletcher_bigendian": (4, 4, 6), "lib_v18_compact": (2, 3, 4), "lib_latest_chunked": (6, 5, 9), "lib_latest_paged": (10, 10, 9),
     "lib_latest_implicit": (4, 5, 6), "lib_latest_single_chunk": (3, 4, 5), "lib_fill_value": (4, 6, 8), "lib_many_attributes": (3, 4, 5),
     "lib_many_variables": (3, 4, 5), "lib_hundred_variables": (2, 3, 4),
+    "lib_f64_shuffle_deflate": (5, 4, 7), "lib_i16_bigendian": (3, 3, 5), "lib_u8_chunked": (4, 4, 4),
 }
 
 
@@ -37,12 +38,31 @@ def golden_values(z, y, x):
     return ((((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(8)).astype(np.float32) / np.float32(16777216.0)).reshape(4, z, y, x)
 
 
-@pytest.mark.parametrize("name", sorted(LIB_FILES))
-def test_reader_on_files_written_by_libhdf5(name):
+def golden_hash(z, y, x):
+    return (np.arange(4 * z * y * x, dtype=np.uint64) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+
+
+def expected(name):
+    """what a reader must hand over for a golden file: f32, converted from the stored type as netcdf-c's nc_get_vara_float converts
+    (the reference reads with get::<f32>, loaders/netcdf.rs:45)"""
     z, y, x = LIB_FILES[name]
     want = golden_values(z, y, x)
     if name == "lib_fill_value":
         want[:, 2:] = NC_FILL_FLOAT                      # only z < 2 was written: the other chunks do not exist
+    elif name == "lib_f64_shuffle_deflate":
+        want = (golden_hash(z, y, x).astype(np.float64) / 4294967296.0).astype(np.float32).reshape(4, z, y, x)   # (float)double
+        assert (want.astype(np.float64) != golden_hash(z, y, x).reshape(4, z, y, x) / 4294967296.0).any()        # ... really rounds
+    elif name == "lib_i16_bigendian":
+        want = (golden_hash(z, y, x) >> np.uint64(16)).astype(np.uint16).view(np.int16).astype(np.float32).reshape(4, z, y, x)
+        assert (want < 0).any()
+    elif name == "lib_u8_chunked":
+        want = (golden_hash(z, y, x) >> np.uint64(24)).astype(np.float32).reshape(4, z, y, x)
+    return want
+
+
+@pytest.mark.parametrize("name", sorted(LIB_FILES))
+def test_reader_on_files_written_by_libhdf5(name):
+    want = expected(name)
     got = netcdf.read_color(os.path.join(GOLDEN, name + ".nc"))
     assert got.shape == want.shape
     assert got.tobytes() == want.tobytes()

@@ -82,6 +82,44 @@ def test_reads_cdf5(tmp_path):
     assert np.array_equal(netcdf.read_color(p), d)
 
 
+@pytest.mark.parametrize("code", ["d", "i", "h", "b"])
+def test_other_numeric_types_are_converted_like_netcdf_c(tmp_path, code):
+    """loaders/netcdf.rs:45 reads with get::<f32>, i.e. nc_get_vara_float: netcdf-c hands any numeric external type over as
+    (float)value.  Files by scipy.io.netcdf_file with `color` as double, int, short, byte."""
+    rng = np.random.default_rng(7)
+    if code == "d":
+        v = rng.random((4, 3, 4, 5)) * 2.0 - 0.5             # 53-bit fractions: the cast rounds
+    else:
+        lim = {"i": 2 ** 31 - 1, "h": 2 ** 15 - 1, "b": 127}[code]
+        v = rng.integers(-lim - 1, lim + 1, (4, 3, 4, 5))
+    p = os.path.join(tmp_path, "typed.nc")
+    f = scipy_io.netcdf_file(p, "w")
+    for n, k in zip("czyx", v.shape):
+        f.createDimension(n, k)
+    var = f.createVariable("color", code, ("c", "z", "y", "x"))
+    var[:] = v
+    want = np.array(var[:]).astype(np.float32)
+    f.close()
+    got = netcdf.read_color(p)
+    assert got.dtype == np.float32 and got.tobytes() == want.tobytes()
+    if code == "d":
+        assert (want.astype(np.float64) != v).any()
+
+
+def test_double_beyond_float_range_is_an_error(tmp_path):
+    """nc_get_vara_float returns NC_ERANGE for a double no float can hold, and the reference's `?` fails the load"""
+    p = os.path.join(tmp_path, "huge.nc")
+    f = scipy_io.netcdf_file(p, "w")
+    for n, k in zip("czyx", (4, 2, 2, 2)):
+        f.createDimension(n, k)
+    v = np.zeros((4, 2, 2, 2))
+    v[1, 1, 0, 1] = 1e300
+    f.createVariable("color", "d", ("c", "z", "y", "x"))[:] = v
+    f.close()
+    with pytest.raises(VrmError, match="NC_ERANGE"):
+        netcdf.read_color(p)
+
+
 def test_errors(tmp_path):
     with pytest.raises(VrmError):
         netcdf.read_color(os.path.join(tmp_path, "missing.nc"))
@@ -102,13 +140,13 @@ def test_errors(tmp_path):
     f.close()
     with pytest.raises(VrmError, match="color"):
         netcdf.read_color(p)
-    p = os.path.join(tmp_path, "double.nc")
+    p = os.path.join(tmp_path, "text.nc")
     f = scipy_io.netcdf_file(p, "w")
     for n, k in zip("czyx", (4, 2, 2, 2)):
         f.createDimension(n, k)
-    f.createVariable("color", "d", ("c", "z", "y", "x"))[:] = np.zeros((4, 2, 2, 2))
+    f.createVariable("color", "c", ("c", "z", "y", "x"))[:] = np.full((4, 2, 2, 2), b"a")
     f.close()
-    with pytest.raises(VrmError, match="f32"):
+    with pytest.raises(VrmError, match="not numeric"):       # nc_get_vara_float on text: NC_ECHAR
         netcdf.read_color(p)
     p = os.path.join(tmp_path, "order.nc")
     f = scipy_io.netcdf_file(p, "w")

@@ -20,6 +20,10 @@
  *   lib_latest_single_chunk.nc   z,y,x = 3,4,5   latest bounds, one chunk of the dataset's size, deflate
  *   lib_fill_value.nc            z,y,x = 4,6,8   chunks (4,2,3,4), fill value 9.96921e+36 (netCDF's NC_FILL_FLOAT) defined, and only the hyperslab
  *                                                z < 2 written: the other chunks do not exist and read as the fill value
+ *   lib_f64_shuffle_deflate.nc   z,y,x = 5,4,7   `color` stored as little-endian binary64 (values i*2654435761 mod 2^32 / 2^32, which binary32 cannot hold:
+ *                                                the reader hands them over as (float)value, like nc_get_vara_float), chunks (2,2,3,4), shuffle over 8 bytes
+ *   lib_i16_bigendian.nc         z,y,x = 3,3,5   `color` as big-endian signed 16-bit integers (the hash's top 16 bits), contiguous
+ *   lib_u8_chunked.nc            z,y,x = 4,4,4   `color` as unsigned bytes (the hash's top 8 bits), chunks (2,4,2,4)
  *   lib_many_attributes.nc       z,y,x = 3,4,5   v18 bounds, 12 attributes on `color`: dense attribute storage (fractal heap + B-tree v2)
  *   lib_many_variables.nc        z,y,x = 3,4,5   v18 bounds, 10 more datasets in the root group: dense link storage
  *   lib_hundred_variables.nc     z,y,x = 2,3,4   120 more: the link heap's root is an indirect block, the name index a B-tree of depth 1
@@ -64,6 +68,8 @@ static void attr_str(hid_t obj, const char *name, const char *text)
 }
 
 enum { CONTIGUOUS, CHUNKED, COMPACT };
+enum { AS_F32, AS_F64, AS_I16BE, AS_U8 };
+static int stored_as = AS_F32; /* the file type of `color` in the next make() */
 
 enum { MANY_ATTRIBUTES = 1, MANY_VARIABLES = 2, ALLOC_EARLY = 4, PARTIAL_WITH_FILL = 8, HUNDRED_VARIABLES = 16 };
 
@@ -115,10 +121,25 @@ static void make(const char *dir, const char *name, hsize_t z, hsize_t y, hsize_
         const float nc_fill = 9.9692099683868690e+36f;
         CHECK(H5Pset_fill_value(dcpl, H5T_NATIVE_FLOAT, &nc_fill));
     }
-    hid_t color = H5Dcreate2(f, "color", big_endian ? H5T_IEEE_F32BE : H5T_IEEE_F32LE, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+    hid_t ftype = stored_as == AS_F64 ? H5T_IEEE_F64LE : stored_as == AS_I16BE ? H5T_STD_I16BE : stored_as == AS_U8 ? H5T_STD_U8LE
+                : big_endian ? H5T_IEEE_F32BE : H5T_IEEE_F32LE;
+    hid_t color = H5Dcreate2(f, "color", ftype, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
     CHECK(color);
     const size_t n = (size_t)(4 * z * y * x);
     float *v = values(n);
+    if (stored_as != AS_F32) {
+        /* written from memory of the file's own type: no conversion on the way in */
+        void *w = malloc(n * 8);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t hsh = (uint32_t)i * 2654435761u;
+            if (stored_as == AS_F64) ((double *)w)[i] = (double)hsh / 4294967296.0;
+            else if (stored_as == AS_I16BE) ((int16_t *)w)[i] = (int16_t)(hsh >> 16);
+            else ((uint8_t *)w)[i] = (uint8_t)(hsh >> 24);
+        }
+        CHECK(H5Dwrite(color, stored_as == AS_F64 ? H5T_NATIVE_DOUBLE : stored_as == AS_I16BE ? H5T_NATIVE_INT16 : H5T_NATIVE_UINT8, H5S_ALL, H5S_ALL,
+                       H5P_DEFAULT, w));
+        free(w);
+    } else
     if (extras & PARTIAL_WITH_FILL) {
         /* z < 2 only; the values are those of the full array at the same places */
         const hsize_t start[4] = {0, 0, 0, 0}, count[4] = {4, 2, y, x};
@@ -180,6 +201,14 @@ int main(int argc, char **argv)
     make(d, "lib_latest_implicit.nc", 4, 5, 6, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST, CHUNKED, c6, 0, 0, 0, 0, ALLOC_EARLY);
     make(d, "lib_latest_single_chunk.nc", 3, 4, 5, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST, CHUNKED, c7, 0, 3, 0, 0, 0);
     make(d, "lib_fill_value.nc", 4, 6, 8, H5F_LIBVER_EARLIEST, H5F_LIBVER_V18, CHUNKED, c8, 0, 0, 0, 0, PARTIAL_WITH_FILL);
+    const hsize_t c9[4] = {2, 2, 3, 4}, c10[4] = {2, 4, 2, 4};
+    stored_as = AS_F64;
+    make(d, "lib_f64_shuffle_deflate.nc", 5, 4, 7, H5F_LIBVER_EARLIEST, H5F_LIBVER_V18, CHUNKED, c9, 1, 5, 0, 0, 0);
+    stored_as = AS_I16BE;
+    make(d, "lib_i16_bigendian.nc", 3, 3, 5, H5F_LIBVER_V18, H5F_LIBVER_V18, CONTIGUOUS, NULL, 0, 0, 0, 0, 0);
+    stored_as = AS_U8;
+    make(d, "lib_u8_chunked.nc", 4, 4, 4, H5F_LIBVER_EARLIEST, H5F_LIBVER_V18, CHUNKED, c10, 0, 0, 0, 0, 0);
+    stored_as = AS_F32;
     make(d, "lib_many_attributes.nc", 3, 4, 5, H5F_LIBVER_V18, H5F_LIBVER_V18, CONTIGUOUS, NULL, 0, 0, 0, 0, MANY_ATTRIBUTES);
     make(d, "lib_many_variables.nc", 3, 4, 5, H5F_LIBVER_V18, H5F_LIBVER_V18, CONTIGUOUS, NULL, 0, 0, 0, 0, MANY_VARIABLES);
     make(d, "lib_hundred_variables.nc", 2, 3, 4, H5F_LIBVER_V18, H5F_LIBVER_V18, CONTIGUOUS, NULL, 0, 0, 0, 0, MANY_VARIABLES | HUNDRED_VARIABLES);

@@ -11,7 +11,8 @@
 //   * groups as a symbol table (B-tree version 1 "TREE" of "SNOD" nodes + local "HEAP"), as compact link messages
 //     (what netcdf-c's creation-order tracking produces for a handful of objects) and as dense link storage (more than
 //     8 objects: fractal heap "FRHP" + version-2 B-tree name index, up to about a thousand links);
-//   * the dataset's dataspace (versions 1, 2), datatype (IEEE f32, little or big endian), fill value, and data layout
+//   * the dataset's dataspace (versions 1, 2), datatype (IEEE f32; also f64 and integers of 1-8 bytes, converted to f32 the way
+//     netcdf-c's nc_get_vara_float does for the reference's get_values::<f32>; little or big endian), fill value, and data layout
 //     message version 3 -- compact, contiguous, or chunked through a version-1 chunk B-tree -- and version 4: compact,
 //     contiguous, single-chunk, implicit and fixed-array chunk indexes (the indexes of datasets with unlimited dimensions,
 //     extensible array and version-2 B-tree, are recognised and refused);
@@ -354,11 +355,18 @@ void group_links(H5 &h, const std::vector<Message> &msgs, Links &links)
 struct Dataset {
     std::vector<uint64_t> dims;
     bool big_endian = false;
+    // the stored element: IEEE float of 4 or 8 bytes, or an integer of 1, 2, 4 or 8 bytes; whatever it is, the variable is handed
+    // over as f32 the way netcdf-c's nc_get_vara_float -- what the reference's get_values::<f32> (netcdf.rs:45) calls -- converts it
+    size_t esize = 4;
+    bool is_float = true, is_signed = true;
+    uint64_t chunk_elem = 0;   // the element size the layout message states (checked against the datatype once both are known)
+    uint32_t shuffle_size = 0; // the shuffle filter's own element size
     int layout = -1; // 0 compact, 1 contiguous, 2 chunked (B-tree v1), 3 single chunk, 4 implicit chunk index, 5 fixed-array chunk index
     uint64_t addr = UNDEF, size = 0;
     std::vector<uint8_t> compact; // layout 0: the data itself, from the layout message
     bool filtered_index = false;  // layout 5: the index entries carry a stored size and a filter mask
-    uint8_t fill[4] = {0, 0, 0, 0}; // the dataset's fill value in the FILE's byte order (what never-written storage reads as)
+    uint8_t fill[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // the dataset's fill value as stored, `esize` bytes (what never-written storage reads as)
+    size_t fill_size = 0;
     std::vector<uint64_t> chunk; // chunk dims (elements), rank entries
     struct Filter { uint16_t id; };
     std::vector<Filter> filters;
@@ -383,12 +391,24 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
         } else if (m.type == 0x0003) { // datatype
             const uint64_t cv = c.u(1), b0 = c.u(1);
             c.skip(2);
-            const uint64_t size = c.u(4);
-            if ((cv & 0x0f) != 1 || size != 4) h.fail("variable 'color' is not a 4-byte floating-point dataset (class %llu, size %llu)", (unsigned long long)(cv & 0x0f), (unsigned long long)size);
+            const uint64_t size = c.u(4), cls = cv & 0x0f;
             d.big_endian = b0 & 1;
-            c.u(2);
-            const uint64_t prec = c.u(2), eloc = c.u(1), esz = c.u(1), mloc = c.u(1), msz = c.u(1), bias = c.u(4);
-            if (prec != 32 || eloc != 23 || esz != 8 || mloc != 0 || msz != 23 || bias != 127) h.fail("variable 'color' is not IEEE binary32");
+            d.esize = (size_t)size;
+            if (cls == 1 && (size == 4 || size == 8)) {
+                c.u(2);
+                const uint64_t prec = c.u(2), eloc = c.u(1), esz = c.u(1), mloc = c.u(1), msz = c.u(1), bias = c.u(4);
+                const bool f32 = size == 4 && prec == 32 && eloc == 23 && esz == 8 && mloc == 0 && msz == 23 && bias == 127;
+                const bool f64 = size == 8 && prec == 64 && eloc == 52 && esz == 11 && mloc == 0 && msz == 52 && bias == 1023;
+                if (!f32 && !f64) h.fail("variable 'color' is neither IEEE binary32 nor binary64");
+                d.is_float = true;
+            } else if (cls == 0 && (size == 1 || size == 2 || size == 4 || size == 8)) {
+                const uint64_t bit_off = c.u(2), prec = c.u(2);
+                if (bit_off != 0 || prec != 8 * size) h.fail("variable 'color' is an integer of %llu bits in %llu bytes", (unsigned long long)prec, (unsigned long long)size);
+                d.is_float = false;
+                d.is_signed = (b0 & 0x08) != 0;
+            } else {
+                h.fail("variable 'color' is not a numeric dataset netCDF can hand over as float (datatype class %llu, size %llu)", (unsigned long long)cls, (unsigned long long)size);
+            }
             have_type = true;
         } else if (m.type == 0x0008) { // data layout
             const uint64_t ver = c.u(1);
@@ -403,7 +423,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                     const uint64_t nd = c.u(1);
                     d.addr = c.off();
                     for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u(4));
-                    if (c.u(4) != 4) h.fail("chunk element size is not 4");
+                    d.chunk_elem = c.u(4);
                 } else if (cls == 0) {
                     d.layout = 0;
                     d.size = c.u(2);
@@ -427,7 +447,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                     const uint64_t fl = c.u(1), nd = c.u(1), enc = c.u(1);
                     if (enc < 1 || enc > 8) h.fail("chunk dimension size encoded in %llu bytes", (unsigned long long)enc);
                     for (uint64_t i = 0; i + 1 < nd; ++i) d.chunk.push_back(c.u((int)enc));
-                    c.u((int)enc);
+                    d.chunk_elem = c.u((int)enc);
                     const uint64_t idx = c.u(1);
                     if (idx == 1) { // single chunk
                         d.layout = 3;
@@ -459,7 +479,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
             }
             if (defined && c.left() >= 4) {
                 const uint64_t sz = c.u(4);
-                if (sz == 4 && c.left() >= 4) memcpy(d.fill, c.p, 4);
+                if (sz >= 1 && sz <= 8 && c.left() >= sz) { memcpy(d.fill, c.p, (size_t)sz); d.fill_size = (size_t)sz; }
             }
         } else if (m.type == 0x000B) { // filter pipeline
             const uint64_t ver = c.u(1), n = c.u(1);
@@ -474,6 +494,7 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
                 const uint64_t nv = c.u(2);
                 if (ver == 1) c.skip((size_t)((nlen + 7) & ~7ull));
                 else c.skip((size_t)nlen);
+                if (id == 2 && nv >= 1) { c.need(4); d.shuffle_size = (uint32_t)(c.p[0] | c.p[1] << 8 | c.p[2] << 16 | (uint32_t)c.p[3] << 24); }
                 c.skip((size_t)nv * 4);
                 if (ver == 1 && (nv & 1)) c.skip(4);
                 if (id != 1 && id != 2 && id != 3) h.fail("filter %u is not supported (deflate, shuffle, fletcher32 are)", id);
@@ -482,6 +503,10 @@ Dataset parse_dataset(H5 &h, const std::vector<Message> &msgs)
         }
     }
     if (!have_space || !have_type || d.layout < 0) h.fail("object 'color' is not a dataset (dataspace, datatype or layout message missing)");
+    if (d.chunk_elem != 0 && d.chunk_elem != d.esize) h.fail("chunk element size %llu, datatype size %zu", (unsigned long long)d.chunk_elem, d.esize);
+    if (d.shuffle_size == 0) d.shuffle_size = (uint32_t)d.esize;
+    if (d.shuffle_size > 64) h.fail("shuffle filter over elements of %u bytes", d.shuffle_size);
+    if (d.fill_size != 0 && d.fill_size != d.esize) d.fill_size = 0; // (a fill value of another size than the element: not this dataset's)
     return d;
 }
 
@@ -505,17 +530,53 @@ void decode_chunk(H5 &h, const Dataset &d, uint64_t addr, uint64_t stored, uint3
             if (uncompress(raw.data(), &n, tmp.data(), (uLong)cur) != Z_OK) h.fail("a chunk does not inflate");
             cur = (size_t)n;
             tmp.assign(raw.begin(), raw.begin() + (long)cur);
-        } else if (id == 2) { // shuffle, element size 4
+        } else if (id == 2) { // shuffle: byte b of every element stored together
             raw.resize(cur);
-            const size_t n = cur / 4;
-            for (size_t e = 0; e < n; ++e)
-                for (size_t b = 0; b < 4; ++b) raw[4 * e + b] = tmp[b * n + e];
-            for (size_t r = 4 * n; r < cur; ++r) raw[r] = tmp[r];
-            tmp.assign(raw.begin(), raw.begin() + (long)cur);
+            const size_t E = d.shuffle_size, n = cur / E;
+            if (E > 1) {
+                for (size_t e = 0; e < n; ++e)
+                    for (size_t b = 0; b < E; ++b) raw[E * e + b] = tmp[b * n + e];
+                for (size_t r = E * n; r < cur; ++r) raw[r] = tmp[r];
+                tmp.assign(raw.begin(), raw.begin() + (long)cur);
+            }
         }
     }
     if (cur != chunk_bytes) h.fail("a chunk decodes to %zu bytes, expected %zu", cur, chunk_bytes);
     raw.assign(tmp.begin(), tmp.begin() + (long)cur);
+}
+
+// n stored elements -> f32, as netcdf-c converts on nc_get_vara_float: a C cast of the value (round to nearest for binary64 and for
+// integers beyond 2^24)
+// (nc4_convert_type counts a binary64 beyond +-FLT_MAX as a range error and the read returns NC_ERANGE, which the reference's `?`
+// turns into a failed load: `range_errors` carries that count)
+thread_local size_t range_errors = 0;
+void to_f32(const Dataset &d, const uint8_t *src, float *dst, size_t n)
+{
+    const size_t E = d.esize;
+    if (d.is_float && E == 4 && !d.big_endian) {
+        memcpy(dst, src, n * 4);
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t v = 0;
+        const uint8_t *p = src + i * E;
+        if (d.big_endian) for (size_t b = 0; b < E; ++b) v = (v << 8) | p[b];
+        else for (size_t b = 0; b < E; ++b) v |= (uint64_t)p[b] << (8 * b);
+        if (d.is_float) {
+            if (E == 4) { const uint32_t w = (uint32_t)v; memcpy(dst + i, &w, 4); }
+            else {
+                double x;
+                memcpy(&x, &v, 8);
+                if (x > 3.402823466e+38 || x < -3.402823466e+38) ++range_errors; // (infinities included, as netcdf-c's comparison has it; NaN passes)
+                dst[i] = (float)x;
+            }
+        } else if (d.is_signed) {
+            const int sh = 64 - 8 * (int)E;
+            dst[i] = (float)((int64_t)(v << sh) >> sh);
+        } else {
+            dst[i] = (float)v;
+        }
+    }
 }
 
 void copy_chunk(const Dataset &d, const std::vector<uint64_t> &origin, const uint8_t *raw, float *out)
@@ -529,16 +590,16 @@ void copy_chunk(const Dataset &d, const std::vector<uint64_t> &origin, const uin
     for (uint64_t a = 0; a < C[0] && origin[0] + a < D[0]; ++a)
         for (uint64_t b = 0; b < C[1] && origin[1] + b < D[1]; ++b)
             for (uint64_t c = 0; c < C[2] && origin[2] + c < D[2]; ++c) {
-                const uint8_t *src = raw + 4 * (((a * C[1] + b) * C[2] + c) * C[3]);
+                const uint8_t *src = raw + d.esize * (((a * C[1] + b) * C[2] + c) * C[3]);
                 float *dst = out + (((origin[0] + a) * D[1] + origin[1] + b) * D[2] + origin[2] + c) * D[3] + origin[3];
-                memcpy(dst, src, (size_t)n3 * 4);
+                to_f32(d, src, dst, (size_t)n3);
             }
 }
 
 void read_chunked(H5 &h, const Dataset &d, float *out)
 {
     if (d.chunk.size() != 4) h.fail("chunk rank %zu, expected 4", d.chunk.size());
-    size_t chunk_bytes = 4;
+    size_t chunk_bytes = d.esize;
     for (uint64_t c : d.chunk) {
         if (c == 0 || c > ((uint64_t)1 << 31)) h.fail("bad chunk dimension");
         if (chunk_bytes > ((size_t)1 << 32) / (size_t)c) h.fail("chunk too large");
@@ -754,31 +815,41 @@ int vrm_hdf5_read_color(FILE *f, const char *path, uint32_t *x, uint32_t *y, uin
             vrm_set_error("%s holds %llu floats, buffer holds %zu", path, (unsigned long long)n, capacity_floats);
             return VRM_ERR_INVALID;
         }
+        const uint64_t E = d.esize;
+        range_errors = 0;
         auto fill_all = [&] { // storage that was never written reads as the dataset's fill value (zero bytes unless the file defines one)
+            float v = 0.0f;
+            if (d.fill_size) to_f32(d, d.fill, &v, 1);
             uint32_t w;
-            memcpy(&w, d.fill, 4);
+            memcpy(&w, &v, 4);
             if (w == 0) memset(out, 0, (size_t)n * 4);
             else for (uint64_t i = 0; i < n; ++i) memcpy(out + i, &w, 4);
         };
         if (d.layout == 0) {
-            if (d.compact.size() < n * 4) h.fail("compact storage of %zu bytes is shorter than the %llu the dimensions need", d.compact.size(), (unsigned long long)(n * 4));
-            memcpy(out, d.compact.data(), (size_t)n * 4);
+            if (d.compact.size() < n * E) h.fail("compact storage of %zu bytes is shorter than the %llu the dimensions need", d.compact.size(), (unsigned long long)(n * E));
+            to_f32(d, d.compact.data(), out, (size_t)n);
         } else if (d.layout == 1) {
             if (d.addr == UNDEF) {
                 fill_all();
             } else {
-                if (d.size < n * 4) h.fail("contiguous storage of %llu bytes is shorter than the %llu the dimensions need", (unsigned long long)d.size, (unsigned long long)(n * 4));
-                const size_t step = (size_t)1 << 26;
-                for (uint64_t done = 0; done < n * 4; done += step) h.read(d.addr + done, reinterpret_cast<uint8_t *>(out) + done, (size_t)std::min<uint64_t>(step, n * 4 - done));
+                if (d.size < n * E) h.fail("contiguous storage of %llu bytes is shorter than the %llu the dimensions need", (unsigned long long)d.size, (unsigned long long)(n * E));
+                const uint64_t step = (uint64_t)1 << 24; // elements per block
+                if (d.is_float && E == 4 && !d.big_endian) {
+                    for (uint64_t done = 0; done < n; done += step) h.read(d.addr + done * 4, reinterpret_cast<uint8_t *>(out + done), (size_t)(std::min<uint64_t>(step, n - done) * 4));
+                } else {
+                    std::vector<uint8_t> blk((size_t)(std::min<uint64_t>(step, n) * E));
+                    for (uint64_t done = 0; done < n; done += step) {
+                        const uint64_t k = std::min<uint64_t>(step, n - done);
+                        h.read(d.addr + done * E, blk.data(), (size_t)(k * E));
+                        to_f32(d, blk.data(), out + done, (size_t)k);
+                    }
+                }
             }
         } else {
             fill_all(); // chunks that were never written
             read_chunked(h, d, out);
         }
-        if (d.big_endian) {
-            uint32_t *w = reinterpret_cast<uint32_t *>(out);
-            for (uint64_t i = 0; i < n; ++i) w[i] = __builtin_bswap32(w[i]);
-        }
+        if (range_errors) h.fail("%zu values of 'color' are binary64 beyond the range of f32: netcdf-c reads them as NC_ERANGE and the reference's load fails", range_errors);
         return VRM_OK;
     } catch (const Fail &e) {
         vrm_set_error("%s", e.msg.c_str());

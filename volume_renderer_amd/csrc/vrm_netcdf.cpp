@@ -93,6 +93,7 @@ struct Reader {
 struct Header {
     uint64_t x = 0, y = 0, z = 0;
     uint64_t begin = 0;
+    uint32_t type = NC_FLOAT; // nc_type of `color`
 };
 
 int read_header(FILE *f, const char *path, Header *h)
@@ -131,7 +132,9 @@ int read_header(FILE *f, const char *path, Header *h)
         r.count();                       // vsize (unreliable beyond 4 GiB by specification: not used)
         const uint64_t begin = r.offset();
         if (name == "color" && r.ok) {   // netcdf.rs:37
-            REQUIRE_IO(type == NC_FLOAT, "%s: variable 'color' is not f32 (nc_type %u)", path, type);
+            // (netcdf.rs:45 reads with get_values::<f32>: netcdf-c converts every numeric external type; text it refuses, NC_ECHAR)
+            REQUIRE_IO(type != 2 && Reader::type_size(type) != 0, "%s: variable 'color' is not numeric (nc_type %u)", path, type);
+            h->type = type;
             REQUIRE_IO(nd == 4, "%s: variable 'color' has %llu dimensions, expected (c, z, y, x)", path, (unsigned long long)nd);
             const char *want[4] = {"c", "z", "y", "x"};
             for (int i = 0; i < 4; ++i) {
@@ -202,7 +205,7 @@ extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y,
     *z = (uint32_t)h.z;
     struct stat st;
     REQUIRE_IO(fstat(fileno(fl.f), &st) == 0 && (uint64_t)st.st_size >= h.begin &&
-                   !mul3_overflows(h.x, h.y, h.z) && ((uint64_t)st.st_size - h.begin) / 16 >= h.x * h.y * h.z,   // (x, y, z < 2^32 each: the product of THREE can wrap 64 bits)
+                   !mul3_overflows(h.x, h.y, h.z) && ((uint64_t)st.st_size - h.begin) / (4 * Reader::type_size(h.type)) >= h.x * h.y * h.z,   // (x, y, z < 2^32 each: the product of THREE can wrap 64 bits)
                "%s: data of 'color' is truncated: the header promises color(4,%llu,%llu,%llu) but the file has only %lld bytes", path, (unsigned long long)h.z,
                (unsigned long long)h.y, (unsigned long long)h.x, (long long)st.st_size);
     if (!color_czyx) return VRM_OK; // size query
@@ -213,12 +216,39 @@ extern "C" int vrm_netcdf_read_color(const char *path, uint32_t *x, uint32_t *y,
     }
     REQUIRE_IO(fseeko(fl.f, (off_t)h.begin, SEEK_SET) == 0, "%s: cannot seek to the data of 'color'", path);
     const size_t chunk = (size_t)1 << 22;
+    if (h.type == NC_FLOAT) {
+        for (size_t done = 0; done < n; done += chunk) {
+            const size_t k = n - done < chunk ? n - done : chunk;
+            REQUIRE_IO(fread(color_czyx + done, 4, k, fl.f) == k, "%s: data of 'color' is truncated", path);
+            uint32_t *w = reinterpret_cast<uint32_t *>(color_czyx + done);
+            for (size_t i = 0; i < k; ++i) w[i] = bswap32(w[i]); // XDR: big-endian IEEE
+        }
+        return VRM_OK;
+    }
+    // any other numeric type: big-endian on disk, handed over as (float)value like nc_get_vara_float
+    const size_t E = (size_t)Reader::type_size(h.type);
+    const bool is_double = h.type == 6, is_signed = h.type == 1 || h.type == 3 || h.type == 4 || h.type == 10;
+    std::vector<uint8_t> blk(chunk * E);
+    size_t range_errors = 0; // (ncx_getn_double_float: a double beyond +-FLT_MAX is NC_ERANGE, and the reference's `?` fails the load)
     for (size_t done = 0; done < n; done += chunk) {
         const size_t k = n - done < chunk ? n - done : chunk;
-        REQUIRE_IO(fread(color_czyx + done, 4, k, fl.f) == k, "%s: data of 'color' is truncated", path);
-        uint32_t *w = reinterpret_cast<uint32_t *>(color_czyx + done);
-        for (size_t i = 0; i < k; ++i) w[i] = bswap32(w[i]); // XDR: big-endian IEEE
+        REQUIRE_IO(fread(blk.data(), E, k, fl.f) == k, "%s: data of 'color' is truncated", path);
+        for (size_t i = 0; i < k; ++i) {
+            uint64_t v = 0;
+            for (size_t b = 0; b < E; ++b) v = (v << 8) | blk[i * E + b];
+            float out;
+            if (is_double) {
+                double x;
+                memcpy(&x, &v, 8);
+                if (x > 3.402823466e+38 || x < -3.402823466e+38) ++range_errors;
+                out = (float)x;
+            }
+            else if (is_signed) { const int sh = 64 - 8 * (int)E; out = (float)((int64_t)(v << sh) >> sh); }
+            else out = (float)v;
+            color_czyx[done + i] = out;
+        }
     }
+    REQUIRE_IO(range_errors == 0, "%s: %zu values of 'color' are doubles beyond the range of f32 (NC_ERANGE: the reference's load fails)", path, range_errors);
     return VRM_OK;
     });
 }
