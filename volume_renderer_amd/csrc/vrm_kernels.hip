@@ -16,6 +16,9 @@
 #pragma clang fp contract(off)
 
 #ifndef VRM_CAP_DEFAULT
+#ifndef VRM_PK_ASM
+#define VRM_PK_ASM 1 /* the RGBA filter's packed lerps written out, the weights in ONE register pair (0: left to the compiler; A/B) */
+#endif
 #define VRM_CAP_DEFAULT 2560 /* LDS words per wave of the default march (A/B builds override it) */
 #endif
 #ifndef VRM_CAP_PACKED
@@ -248,7 +251,48 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
         return __builtin_fmaf(wz, c1 - c0, c0);
     };
 #endif
+#if VRM_PK_ASM && !VRM_WEIGHTS_FIRST
+    // The same lerps as tri(), in the same operations and order (bit-identical: tools/ab_bits.py), written as the packed
+    // instructions the compiler's SLP pass pairs them into, but with the weights in ONE register pair {wx * 2^127, wy} picked per
+    // instruction by op_sel: the compiler builds a {w, w} pair per weight instead, two v_mov per sample (84 -> 82 VALU
+    // instructions in the step body, 123 -> 121 VGPRs; C3 -1.9 %, profiles/r3/pk_asm.txt).  Pairs: one channel of two rows (y0z0
+    // with y0z1, y1z0 with y1z1: the y-lerp then runs in both halves and leaves {value at z = 0, value at z = 1}), or red and
+    // green of one row.  One statement per x-y stage: the compiler pads every inline-assembly result that the next instruction
+    // reads with an s_nop (17 per sample as single-instruction statements, 5 so; dependent v_pk_*_f32 need none on gfx950).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 wq = {wxs, wy};
+    f2 wzq;
+    wzq.x = wz; // (the high half is never read: op_sel_hi = 0 on this operand)
+    // lo = fma(dlo, wxs, alo), hi = fma(dhi, wxs, ahi), then fma(wy, hi - lo, lo), each in both halves
+    auto xyl = [&](f2 dlo, f2 alo, f2 dhi, f2 ahi) -> f2 {
+        f2 lo, t, r;
+        asm("v_pk_fma_f32 %0, %3, %7, %4 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %1, %5, %7, %6 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_add_f32 %1, %1, %0 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %2, %7, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+            : "=&v"(lo), "=&v"(t), "=&v"(r) : "v"(dlo), "v"(alo), "v"(dhi), "v"(ahi), "v"(wq));
+        return r;
+    };
+    auto rows_a = [&](auto kc, int i, int j) -> f2 { constexpr int k = decltype(kc)::value; return f2{byte_scaled<k>(c[2 * i]), byte_scaled<k>(c[2 * j])}; };
+    auto rows_d = [&](auto kc, int i, int j) -> f2 {
+        constexpr int k = decltype(kc)::value;
+        return f2{byte_diff<k>(c[2 * i + 1], c[2 * i]), byte_diff<k>(c[2 * j + 1], c[2 * j])};
+    };
+    auto rg_a = [&](int i) -> f2 { return f2{byte_scaled<0>(c[2 * i]), byte_scaled<1>(c[2 * i])}; };
+    auto rg_d = [&](int i) -> f2 { return f2{byte_diff<0>(c[2 * i + 1], c[2 * i]), byte_diff<1>(c[2 * i + 1], c[2 * i])}; };
+    // channel k of rows (i, j) against rows (i + 1, j + 1): x-lerps, then the y-lerp in both halves
+    auto rows_xy = [&](auto kc, int i, int j) -> f2 {
+        return xyl(rows_d(kc, i, j), rows_a(kc, i, j), rows_d(kc, i + 1, j + 1), rows_a(kc, i + 1, j + 1));
+    };
+    // red and green of rows i (y = 0) and i + 1 (y = 1)
+    auto rg_xy = [&](int i) -> f2 { return xyl(rg_d(i), rg_a(i), rg_d(i + 1), rg_a(i + 1)); };
+    const f2 a01 = rows_xy(std::integral_constant<int, 3>{}, 0, 2); // rows y0z0, y0z1 against y1z0, y1z1
+    const float a22 = __builtin_fmaf(wz, a01.y - a01.x, a01.x);
+    (void)rg_xy;
+    (void)tri;
+#else
     const float a22 = tri(std::integral_constant<int, 3>{});
+#endif
     if (a_out) *a_out = a22;
     // alpha_src = 1 - exp(-a*step*att) = 1 - exp2(a22 * kexp22)
     const float e = __builtin_amdgcn_exp2f(a22 * kexp22);
@@ -265,9 +309,22 @@ __device__ __forceinline__ bool shade(const uint32_t c[8], float wx, float wy, f
     } else if (__builtin_amdgcn_ballot_w64(a22 != 0.0f) != 0ull) {
         // a == 0 => alpha_src = 0 => w = 0 => the colour terms add exactly 0: filter r,g,b only when some
         // lane of the wave has a non-zero alpha (wave-uniform branch, three quarters of the filter work)
+#if VRM_PK_ASM && !VRM_WEIGHTS_FIRST
+        // red and green of a row as one pair, blue of two rows as one pair (see the helpers above)
+        const f2 rg0 = rg_xy(0), rg1 = rg_xy(2); // z = 0, z = 1
+        f2 t, rgz;
+        asm("v_pk_add_f32 %0, %2, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_fma_f32 %1, %4, %0, %3 op_sel_hi:[0,1,1]" : "=&v"(t), "=&v"(rgz) : "v"(rg1), "v"(rg0), "v"(wzq));
+        const f2 b01 = rows_xy(std::integral_constant<int, 2>{}, 0, 2);
+        const float bz = __builtin_fmaf(wz, b01.y - b01.x, b01.x);
+        acc.cr = __builtin_fmaf(w, rgz.x, acc.cr);
+        acc.cg = __builtin_fmaf(w, rgz.y, acc.cg);
+        acc.cb = __builtin_fmaf(w, bz, acc.cb);
+#else
         acc.cr = __builtin_fmaf(w, tri(std::integral_constant<int, 0>{}), acc.cr);
         acc.cg = __builtin_fmaf(w, tri(std::integral_constant<int, 1>{}), acc.cg);
         acc.cb = __builtin_fmaf(w, tri(std::integral_constant<int, 2>{}), acc.cb);
+#endif
     }
     acc.alpha = TR ? t1 : __builtin_fmaf(om, alpha_src, acc.alpha);
     // wgsl:176.  Without ERT the launcher has established that no sample can reach alpha_src >= 0.5 (attenuation < 690), and
