@@ -259,6 +259,36 @@ def test_parity_step_cap_on_a_long_volume(rm, vr, orc):
             assert got["iters"].max() == 5000
 
 
+def test_rays_that_are_not_a_number_end_like_the_references(rm1, vr, orc):
+    """A camera 1000 box widths away: f32 leaves the centre pixel's near-plane point ON the camera position, its direction is
+    normalize(0) = NaN, and so are t_min and t_max (wgsl:247-299).  The reference marches such a ray through all 5000 iterations
+    without a sample (every comparison of the in-box test is false).  The LDS march derived 0 steps per chunk from the NaN position
+    and, once only such lanes were left in a wave, planned the same chunk for ever -- the default kernel hung (round 3, found by
+    tools/far_sweep.py).  Every variant must end, with the reference's iteration count and its empty pixel; production build and
+    diagnostics build, skipping on and off."""
+    rm = rm1
+    vox = synth.random_rgba8((64, 15, 64), 12345)
+    configure(rm, vox, 100.0, False)
+    W, H = 31, 83
+    cam = orc.camera_uniform(orc.sphere_position(3, 5, 8, 8, 1000.0), target=(0.0, 0.0, 0.0), aspect=W / H)
+    ref = orc.render(vox, cam, W, H, attenuation=100.0, tf=orc.tf_words(False), want_steps=True)
+    assert ref["steps"].max() == 5000 and (ref["steps"] > 0).sum() == 1          # the one NaN ray "hits" (no comparison says miss)
+    geo = orc.geometry(cam, (64, 15, 64), W, H)
+    assert np.isnan(geo[ref["steps"] == 5000][0][:5]).all()
+    try:
+        for skip in (1, 0):
+            rm.set_option(vr.OPT_SKIP_EMPTY, skip)
+            for k in (1, 3, 4, 0):
+                rm.set_option(vr.OPT_KERNEL, k)
+                got = draw(rm, vr, cam, W, H)
+                assert np.array_equal(got["iters"], ref["steps"]), (skip, k)
+                assert np.array_equal(got["rgba8"], ref["rgba8"]), (skip, k)
+                assert np.array_equal(draw(rm, vr, cam, W, H, diag=False)["rgba8"], ref["rgba8"]), (skip, k)
+    finally:
+        rm.set_option(vr.OPT_KERNEL, 1)
+        rm.set_option(vr.OPT_SKIP_EMPTY, 1)
+
+
 def test_parity_wide_field_of_view_per_tile(rm, vr, orc):
     """An 8x8 image: one wave tile spans the whole 45-degree field of view and, from inside the volume, rays of one wave
     leave through different faces -- the lanes do not share a major axis (lockstep fallback of the plane front)."""

@@ -101,7 +101,11 @@ def main():
                 # Only those two families get the wider gate: attenuation 100, or a camera more than 1000 texels from
                 # the volume's origin; every other case is held to the matrix's 1e-4.
                 far_texels = max(abs(float(p_)) for p_ in pos) * min(dims)   # the camera's distance in texels (the unit edge has min(dims) of them)
-                wide = att >= 100.0 or far_texels > 1000.0
+                # (round 3, seed 9104 case 784: the first family is "rays that run into the 5000-step cap through noise", whatever the
+                # attenuation -- a 1 x 33 x 65 volume is a box 65 units long; there the plain global-gather kernel 0, which follows
+                # the oracle's operation sequence, is 1.015e-4 from the oracle itself and the LDS march 1.027e-4)
+                long_rays = max(dims) >= 5 * min(dims)
+                wide = att >= 100.0 or far_texels > 1000.0 or long_rays
                 check(orc, got, vox, cam, W, H, att, tf, f32_tol_scale=2.0 if wide else 1.0)
             else:
                 # the exact `alpha >= 1.0` exit can fire (attenuation >= 693): WHEN it fires depends on the last ulp of a
@@ -115,6 +119,17 @@ def main():
         except AssertionError as e:
             fails += 1
             print("FAIL", desc, "::", str(e)[:300], flush=True)
+            if os.environ.get("FUZZ_DIAG"):
+                # where, and what the other kernel variants say (0 is the plain global-gather march): FUZZ_DIAG=1 ... --only N
+                ref = orc.render(vox, cam, W, H, attenuation=att, tf=orc.tf_words(tf), want_steps=True)
+                for k in (0, 1, 3, 4):
+                    rm.set_option(vr.OPT_KERNEL, k)
+                    g2 = draw(rm, vr, cam, W, H)
+                    d = np.abs(g2["f32"] - ref["f32"])
+                    i = np.unravel_index(int(d.argmax()), d.shape)
+                    print(f"   kernel {k}: max |f32 - oracle| {d.max():.3e} at pixel (y {i[0]}, x {i[1]}) channel {i[2]}: got {g2['f32'][i]:.9g} oracle {ref['f32'][i]:.9g}; "
+                          f"steps there {int(ref['steps'][i[0], i[1]])}; pixel got {g2['f32'][i[0], i[1]].tolist()} oracle {ref['f32'][i[0], i[1]].tolist()}; "
+                          f"channels' max {[float(d[..., c].max()) for c in range(4)]}; 8-bit max {int(np.abs(g2['rgba8'].astype(int) - ref['rgba8'].astype(int)).max())}", flush=True)
         else:
             if case % 10 == 0:
                 print("ok  ", desc, flush=True)

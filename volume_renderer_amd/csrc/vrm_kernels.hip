@@ -1059,7 +1059,26 @@ __device__ __forceinline__ void march_tile(const VrmMarchParams &P, const VrmVie
 #pragma unroll
             for (int r = 0; r < R; ++r) n_lane[r] = lane_steps(kk, r);
         }
-        if (none) empty = true;
+        // Progress guarantee.  The rear-most active lane always takes kk >= 1 steps -- unless its ray parameter is not a number:
+        // aabb_intersect divides by the ray direction (wgsl:247-299), and a camera far enough away that f32 leaves its rays
+        // parallel to an axis, or one that stands in a face plane of the box, gets t_min = NaN or -inf for some pixels.  The
+        // reference marches such a ray through its 5000 iterations without a sample (every comparison of the in-box test is
+        // false); here every step count derived from its position is 0, and once only such lanes are left the wave would plan
+        // the same chunk for ever (found with a camera 1000 box widths away, tools/far_one.py).  A wave none of whose lanes
+        // would step takes lockstep chunks of 8 steps through the global-gather path, whose per-sample in-box test is the
+        // oracle's own: it ends with the iteration count and the (empty) result of the reference.
+        bool stuck = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) stuck = stuck && n_lane[r] <= 0;
+        stuck = __builtin_amdgcn_ballot_w64(!stuck) == 0ull;
+        if (stuck) { // (no box, no emptiness test: the gather path needs neither)
+            kk = 8;
+#pragma unroll
+            for (int r = 0; r < R; ++r) n_lane[r] = active[r] ? min(8, steps_left[r]) : 0;
+            none = false;
+            fits = false;
+            interior = false;
+        } else if (none) empty = true;
         else {
             if (!fits && lvl == 0) { // global-gather fallback chunk: lockstep, 8 steps
                 kk = 8;
