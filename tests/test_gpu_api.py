@@ -406,6 +406,40 @@ def test_netcdf4_hdf5_load(rm1, vr, orc, tmp_path):
         assert np.array_equal(rm1.voxel_grid.download_rgba8(), orc.quantize_netcdf(want)), name
 
 
+def test_degenerate_camera_uniforms_come_back(vr, orc):
+    """Uniforms no host sends on purpose -- NaN, infinities, zeros, 1e30 -- give rays whose parameters are not numbers; the reference
+    marches whatever it gets, and every march variant here must at least END (round 3: the LDS march hung on NaN rays; the whole
+    matrix of variants, builds and volumes is tools/garbage_cameras.py).  Afterwards the context still renders a sane view."""
+    if not have_gpu():
+        pytest.skip("no GPU")
+    W, H = 40, 24
+    good = sphere_cam(orc, 2, 3, aspect=W / H)
+    bad = {"nan": np.full(36, np.nan, np.float32), "inf": np.full(36, np.inf, np.float32), "zeros": np.zeros(36, np.float32),
+           "huge": (good * np.float32(1e30)).astype(np.float32)}
+    for scalar in (False, True):
+        r = vr.RayMarcher(0, W, H)
+        if scalar:
+            r.voxel_grid.upload_scalar(synth.blobs_scalar_u8((40, 33, 21)).reshape(-1), (40, 33, 21), 1)
+        else:
+            r.voxel_grid.upload_rgba8(synth.random_rgba8((40, 33, 21), 3))
+        img = vr.Screenshotter(r, W, H)
+        r.draw(vr.uniform_from_array(good), img)
+        want = img.read().copy()
+        for c in bad.values():
+            for k in (1, 4):
+                for diag in (0, 1):
+                    r.set_option(vr.OPT_KERNEL, k)
+                    r.set_option(vr.OPT_DIAGNOSTICS, diag)
+                    r.draw(vr.uniform_from_array(c), img)
+                    img.read()
+        r.set_option(vr.OPT_KERNEL, 1)
+        r.set_option(vr.OPT_DIAGNOSTICS, 0)
+        r.draw(vr.uniform_from_array(good), img)
+        assert np.array_equal(img.read(), want)
+        img.close()
+        r.close()
+
+
 def test_library_broadcast_single_rank(vr, orc):
     """vrm_comm_* / vrm_grid_broadcast with RCCL bound inside the library.  One rank is all a one-GPU box can run (RCCL
     refuses two ranks on one device): the id, the communicator, a broadcast in which this rank is the root, the
